@@ -1,0 +1,340 @@
+// Asset readers for the scene loader.  The reference goes through assimp, stb
+// and tinyexr (CUDA-PathTracer/tracer/mesh.cpp:4-47, imageio.cpp:12-103);
+// none of those is available here, so these are small readers for the
+// formats the synthetic scenes use: Wavefront OBJ and binary PLY meshes,
+// binary PPM / 8-bit PNG textures, PFM environment maps.
+#include <zlib.h>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include "scene.h"
+
+namespace caster {
+
+namespace {
+
+bool ends_with(const std::string& s, const char* suf) {
+  size_t n = strlen(suf);
+  if (s.size() < n) return false;
+  for (size_t i = 0; i < n; ++i)
+    if (tolower((unsigned char)s[s.size() - n + i]) != suf[i]) return false;
+  return true;
+}
+
+bool read_file(const std::string& path, std::string& out) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in.good()) return false;
+  std::ostringstream ss;
+  ss << in.rdbuf();
+  out = ss.str();
+  return true;
+}
+
+// OBJ: one output vertex per face corner (assimp's OBJ importer does not
+// share vertices unless asked to join them), polygons fan-triangulated.
+bool load_obj(const std::string& path, RawMesh& m, std::string& err) {
+  std::string text;
+  if (!read_file(path, text)) { err = "cannot open mesh \"" + path + "\""; return false; }
+  std::vector<f3> P, N;
+  std::vector<f2> T;
+  bool any_uv = false;
+  const char* s = text.c_str();
+  const char* end = s + text.size();
+  std::vector<int> corner;  // v, vt, vn triples of the current face
+  while (s < end) {
+    const char* le = (const char*)memchr(s, '\n', (size_t)(end - s));
+    if (!le) le = end;
+    while (s < le && (*s == ' ' || *s == '\t')) ++s;
+    if (le - s >= 2 && s[0] == 'v' && (s[1] == ' ' || s[1] == '\t')) {
+      char* e;
+      f3 p;
+      p.x = strtof(s + 2, &e); p.y = strtof(e, &e); p.z = strtof(e, &e);
+      P.push_back(p);
+    } else if (le - s >= 3 && s[0] == 'v' && s[1] == 'n') {
+      char* e;
+      f3 p;
+      p.x = strtof(s + 3, &e); p.y = strtof(e, &e); p.z = strtof(e, &e);
+      N.push_back(p);
+    } else if (le - s >= 3 && s[0] == 'v' && s[1] == 't') {
+      char* e;
+      f2 p;
+      p.x = strtof(s + 3, &e); p.y = strtof(e, &e);
+      T.push_back(p);
+    } else if (le - s >= 2 && s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
+      corner.clear();
+      const char* q = s + 2;
+      while (q < le) {
+        while (q < le && (*q == ' ' || *q == '\t' || *q == '\r')) ++q;
+        if (q >= le) break;
+        int v = 0, vt = 0, vn = 0;
+        char* e;
+        v = (int)strtol(q, &e, 10);
+        if (e == q) break;
+        q = e;
+        if (q < le && *q == '/') {
+          ++q;
+          if (q < le && *q != '/') { vt = (int)strtol(q, &e, 10); q = e; }
+          if (q < le && *q == '/') { ++q; vn = (int)strtol(q, &e, 10); q = e; }
+        }
+        if (v < 0) v = (int)P.size() + v + 1;
+        if (vt < 0) vt = (int)T.size() + vt + 1;
+        if (vn < 0) vn = (int)N.size() + vn + 1;
+        corner.push_back(v); corner.push_back(vt); corner.push_back(vn);
+      }
+      int nc = (int)corner.size() / 3;
+      for (int k = 1; k + 1 < nc; ++k) {
+        int tri[3] = {0, k, k + 1};
+        for (int c = 0; c < 3; ++c) {
+          int v = corner[3 * tri[c]], vt = corner[3 * tri[c] + 1], vn = corner[3 * tri[c] + 2];
+          if (v < 1 || v > (int)P.size()) { err = "bad vertex index in \"" + path + "\""; return false; }
+          if (vn < 1 || vn > (int)N.size()) {
+            err = "mesh \"" + path + "\" has a face without a normal (vn is required)";
+            return false;
+          }
+          m.idx.push_back((int)m.pos.size());
+          m.pos.push_back(P[v - 1]);
+          m.nrm.push_back(N[vn - 1]);
+          if (vt >= 1 && vt <= (int)T.size()) { m.uv.push_back(T[vt - 1]); any_uv = true; }
+          else m.uv.push_back(f2{0.f, 0.f});
+        }
+      }
+    }
+    s = le + 1;
+  }
+  if (!any_uv) m.uv.clear();
+  if (m.idx.empty()) { err = "mesh \"" + path + "\" has no faces"; return false; }
+  return true;
+}
+
+// Binary little-endian PLY with float x,y,z,nx,ny,nz[,s,t|u,v] vertices and
+// `list uchar int|uint vertex_indices` faces.  Vertices stay shared.
+bool load_ply(const std::string& path, RawMesh& m, std::string& err) {
+  std::string data;
+  if (!read_file(path, data)) { err = "cannot open mesh \"" + path + "\""; return false; }
+  size_t hdr_end = data.find("end_header");
+  if (data.compare(0, 3, "ply") != 0 || hdr_end == std::string::npos) {
+    err = "\"" + path + "\" is not a PLY file"; return false;
+  }
+  size_t body = data.find('\n', hdr_end) + 1;
+  std::istringstream hs(data.substr(0, hdr_end));
+  std::string line;
+  int nv = 0, nf = 0, section = 0;
+  std::vector<std::string> vprops;
+  bool binary = false;
+  while (std::getline(hs, line)) {
+    std::istringstream ls(line);
+    std::string w;
+    ls >> w;
+    if (w == "format") { ls >> w; binary = (w == "binary_little_endian"); }
+    else if (w == "element") {
+      std::string name; int cnt;
+      ls >> name >> cnt;
+      if (name == "vertex") { nv = cnt; section = 1; }
+      else if (name == "face") { nf = cnt; section = 2; }
+      else section = 3;
+    } else if (w == "property" && section == 1) {
+      std::string ty, name;
+      ls >> ty >> name;
+      if (ty != "float" && ty != "float32") { err = "PLY vertex properties must be float"; return false; }
+      vprops.push_back(name);
+    }
+  }
+  if (!binary) { err = "only binary_little_endian PLY is supported"; return false; }
+  auto find = [&](const char* a, const char* b) {
+    for (size_t i = 0; i < vprops.size(); ++i) if (vprops[i] == a || vprops[i] == b) return (int)i;
+    return -1;
+  };
+  int ix = find("x", "x"), iy = find("y", "y"), iz = find("z", "z");
+  int inx = find("nx", "nx"), iny = find("ny", "ny"), inz = find("nz", "nz");
+  int iu = find("s", "u"), iv = find("t", "v");
+  if (ix < 0 || iy < 0 || iz < 0 || inx < 0 || iny < 0 || inz < 0) {
+    err = "PLY \"" + path + "\" needs x,y,z,nx,ny,nz"; return false;
+  }
+  size_t stride = vprops.size() * 4;
+  if (body + stride * (size_t)nv > data.size()) { err = "truncated PLY"; return false; }
+  const char* p = data.data() + body;
+  m.pos.resize(nv); m.nrm.resize(nv);
+  if (iu >= 0 && iv >= 0) m.uv.resize(nv);
+  for (int i = 0; i < nv; ++i) {
+    const float* f = (const float*)(p + stride * (size_t)i);
+    float tmp[32];
+    memcpy(tmp, f, stride > sizeof(tmp) ? sizeof(tmp) : stride);
+    m.pos[i] = f3{tmp[ix], tmp[iy], tmp[iz]};
+    m.nrm[i] = f3{tmp[inx], tmp[iny], tmp[inz]};
+    if (!m.uv.empty()) m.uv[i] = f2{tmp[iu], tmp[iv]};
+  }
+  const unsigned char* q = (const unsigned char*)p + stride * (size_t)nv;
+  const unsigned char* qe = (const unsigned char*)data.data() + data.size();
+  m.idx.reserve((size_t)nf * 3);
+  for (int i = 0; i < nf; ++i) {
+    if (q >= qe) { err = "truncated PLY faces"; return false; }
+    int c = *q++;
+    if (q + 4 * c > qe) { err = "truncated PLY faces"; return false; }
+    int32_t id[16];
+    if (c > 16) { err = "PLY polygon too large"; return false; }
+    memcpy(id, q, 4 * (size_t)c);
+    q += 4 * c;
+    for (int k = 1; k + 1 < c; ++k) {
+      int tri[3] = {id[0], id[k], id[k + 1]};
+      for (int t : tri) {
+        if (t < 0 || t >= nv) { err = "bad PLY index"; return false; }
+        m.idx.push_back(t);
+      }
+    }
+  }
+  if (m.idx.empty()) { err = "mesh \"" + path + "\" has no faces"; return false; }
+  return true;
+}
+
+// ---- images ----------------------------------------------------------------
+
+// Decoded 8-bit image, top row first, `comp` interleaved channels.
+struct Image8 { int w = 0, h = 0, comp = 0; std::vector<uint8_t> px; };
+
+bool load_ppm(const std::string& data, Image8& im) {
+  if (data.size() < 2 || data[0] != 'P' || (data[1] != '6' && data[1] != '5')) return false;
+  im.comp = data[1] == '6' ? 3 : 1;
+  size_t p = 2;
+  int vals[3], got = 0;
+  while (got < 3 && p < data.size()) {
+    while (p < data.size() && isspace((unsigned char)data[p])) ++p;
+    if (p < data.size() && data[p] == '#') { while (p < data.size() && data[p] != '\n') ++p; continue; }
+    int v = 0; bool any = false;
+    while (p < data.size() && isdigit((unsigned char)data[p])) { v = v * 10 + (data[p++] - '0'); any = true; }
+    if (!any) return false;
+    vals[got++] = v;
+  }
+  if (got < 3 || vals[2] != 255) return false;
+  ++p;  // single whitespace after maxval
+  im.w = vals[0]; im.h = vals[1];
+  size_t n = (size_t)im.w * im.h * im.comp;
+  if (p + n > data.size()) return false;
+  im.px.assign(data.begin() + p, data.begin() + p + n);
+  return true;
+}
+
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+
+// Non-interlaced 8-bit grey / RGB / RGBA PNG.
+bool load_png(const std::string& data, Image8& im, std::string& err) {
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (data.size() < 8 || memcmp(data.data(), sig, 8) != 0) { err = "not a PNG"; return false; }
+  const uint8_t* d = (const uint8_t*)data.data();
+  size_t p = 8;
+  std::vector<uint8_t> z;
+  int depth = 0, ctype = 0, interlace = 0;
+  while (p + 8 <= data.size()) {
+    uint32_t len = be32(d + p);
+    std::string ty(data, p + 4, 4);
+    if (p + 12 + len > data.size()) break;
+    if (ty == "IHDR") {
+      im.w = (int)be32(d + p + 8); im.h = (int)be32(d + p + 12);
+      depth = d[p + 16]; ctype = d[p + 17]; interlace = d[p + 20];
+    } else if (ty == "IDAT") {
+      z.insert(z.end(), d + p + 8, d + p + 8 + len);
+    } else if (ty == "IEND") break;
+    p += 12 + len;
+  }
+  if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 6)) {
+    err = "PNG must be 8-bit, non-interlaced, grey/RGB/RGBA"; return false;
+  }
+  im.comp = ctype == 0 ? 1 : (ctype == 2 ? 3 : 4);
+  size_t stride = (size_t)im.w * im.comp;
+  std::vector<uint8_t> raw((stride + 1) * im.h);
+  uLongf rawlen = raw.size();
+  if (uncompress(raw.data(), &rawlen, z.data(), z.size()) != Z_OK || rawlen != raw.size()) {
+    err = "PNG inflate failed"; return false;
+  }
+  im.px.resize(stride * im.h);
+  int bpp = im.comp;
+  for (int y = 0; y < im.h; ++y) {
+    const uint8_t* in = raw.data() + (stride + 1) * y;
+    uint8_t* out = im.px.data() + stride * y;
+    const uint8_t* up = y ? out - stride : nullptr;
+    int ft = in[0];
+    for (size_t x = 0; x < stride; ++x) {
+      int a = x >= (size_t)bpp ? out[x - bpp] : 0;
+      int b = up ? up[x] : 0;
+      int c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0;
+      int v = in[1 + x];
+      switch (ft) {
+        case 1: v += a; break;
+        case 2: v += b; break;
+        case 3: v += (a + b) / 2; break;
+        case 4: {
+          int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+          v += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+          break;
+        }
+        default: break;
+      }
+      out[x] = (uint8_t)v;
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+bool load_mesh_file(const std::string& path, RawMesh& out, std::string& err) {
+  if (ends_with(path, ".ply")) return load_ply(path, out, err);
+  return load_obj(path, out, err);
+}
+
+// Texture load as the reference does it (imageio.cpp:12-60, texture.h:11-23):
+// rows flipped so row 0 is the bottom of the image, sRGB -> linear with
+// pow(x, 2.2), then quantised back to 8 bits by truncation.
+bool load_texture_file(const std::string& path, Texture& out, std::string& err) {
+  std::string data;
+  if (!read_file(path, data)) { err = "cannot open texture \"" + path + "\""; return false; }
+  Image8 im;
+  if (!load_ppm(data, im)) {
+    std::string perr;
+    if (!load_png(data, im, perr)) { err = "texture \"" + path + "\": " + perr; return false; }
+  }
+  out.w = im.w; out.h = im.h;
+  out.rgba.resize((size_t)im.w * im.h * 4);
+  const float inv = 1.f / 255.f;
+  for (int y = 0; y < im.h; ++y) {
+    for (int x = 0; x < im.w; ++x) {
+      const uint8_t* src = im.px.data() + ((size_t)(im.h - 1 - y) * im.w + x) * im.comp;
+      float c[4];
+      if (im.comp == 1) { c[0] = c[1] = c[2] = src[0] * inv; c[3] = 1.f; }
+      else if (im.comp == 3) { c[0] = src[0] * inv; c[1] = src[1] * inv; c[2] = src[2] * inv; c[3] = 1.f; }
+      else { c[0] = src[0] * inv; c[1] = src[1] * inv; c[2] = src[2] * inv; c[3] = src[3] * inv; }
+      uint8_t* dst = out.rgba.data() + ((size_t)y * im.w + x) * 4;
+      dst[0] = (uint8_t)(powf(c[0], 2.2f) * 255);
+      dst[1] = (uint8_t)(powf(c[1], 2.2f) * 255);
+      dst[2] = (uint8_t)(powf(c[2], 2.2f) * 255);
+      dst[3] = (uint8_t)(c[3] * 255);
+    }
+  }
+  return true;
+}
+
+// PFM (PF, 3 x float32, bottom row first when the scale is negative = little
+// endian).  Stored top row first, like the row order tinyexr hands to the
+// reference (imageio.cpp:81-103).
+bool load_envmap_file(const std::string& path, Infinite& out, std::string& err) {
+  std::string data;
+  if (!read_file(path, data)) { err = "cannot open environment map \"" + path + "\""; return false; }
+  if (data.size() < 3 || data[0] != 'P' || data[1] != 'F') {
+    err = "environment map \"" + path + "\" must be a PFM (PF) file"; return false;
+  }
+  int w = 0, h = 0; float scale = 0.f; int consumed = 0;
+  if (sscanf(data.c_str() + 2, "%d %d %f%n", &w, &h, &scale, &consumed) != 3 || w <= 0 || h <= 0) {
+    err = "bad PFM header"; return false;
+  }
+  size_t p = 2 + (size_t)consumed + 1;
+  if (scale > 0.f) { err = "big-endian PFM is not supported"; return false; }
+  if (p + (size_t)w * h * 12 > data.size()) { err = "truncated PFM"; return false; }
+  out.w = w; out.h = h;
+  out.data.resize((size_t)w * h);
+  for (int y = 0; y < h; ++y)
+    memcpy(&out.data[(size_t)(h - 1 - y) * w], data.data() + p + (size_t)y * w * 12, (size_t)w * 12);
+  out.valid = 1;
+  return true;
+}
+
+}  // namespace caster
