@@ -1,0 +1,269 @@
+"""Host-side mirror of the reference's render interface over libcaster.so.
+
+The reference drives its device code through three free functions,
+``BeginRender / Render / EndRender`` (CUDA-PathTracer/tracer/pathtracer.h:8-10),
+wrapped by the ``CudaRender`` singleton (CUDA-PathTracer/tracer/CudaRender.h:9-19:
+``InitCudaScene, renderImage, GetRenderReverseImage, GetConfig, SaveImage,
+GetIteration``).  This module offers the same names and argument meaning over the
+C-ABI of ``include/caster.h``; all rendering happens in the HIP library, and
+importing a renderer fails loudly if that library has not been built.
+
+Images are numpy arrays of shape (H, W, 3), float32, row 0 = bottom scanline as
+the reference's kernels write them; ``GetRenderReverseImage`` returns the
+top-row-first flip the reference hands to its window.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcaster.so")
+
+IT_AO, IT_PT, IT_VPT = 0, 1, 2
+INTEGRATOR_NAMES = {0: "ao", 1: "pt", 2: "vpt"}
+
+
+class CasterError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("caster error %d: %s" % (code, message))
+        self.code = code
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "integrator", "max_depth", "n_prims", "n_nodes", "n_lights", "n_materials",
+        "n_media", "n_textures", "has_environment", "filmic")] + [("max_dist", C.c_float), ("epsilon", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64 * 4), ("samples", C.c_uint64), ("invalid", C.c_uint64),
+                ("stack_overflow", C.c_uint64)]
+
+    def as_dict(self):
+        return {"rays": list(self.rays), "samples": self.samples, "invalid": self.invalid,
+                "stack_overflow": self.stack_overflow}
+
+
+_lib = None
+
+# every symbol include/caster.h declares
+EXPORTS = [
+    "caster_scene_load", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_set_rows",
+    "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
+    "caster_film_add_device", "caster_primary_ids", "caster_get_stats", "caster_reset_stats",
+    "caster_iterations", "caster_end", "caster_last_error",
+]
+
+
+def lib():
+    """Loads libcaster.so (no fallback: the HIP library is the only implementation)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `make -C cuda-pathtracer_amd/csrc` "
+                              "(or __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, fp = C.c_void_p, C.POINTER(C.c_float)
+        L.caster_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.caster_scene_free.argtypes = [vp]
+        L.caster_scene_free.restype = None
+        L.caster_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+        L.caster_begin.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.caster_set_rows.argtypes = [vp, C.c_int, C.c_int]
+        L.caster_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
+        L.caster_render_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
+        L.caster_sync.argtypes = [vp]
+        L.caster_read_film.argtypes = [vp, fp, C.c_int]
+        L.caster_read_film_device.argtypes = [vp, vp, C.c_int]
+        L.caster_film_add_device.argtypes = [vp, vp, C.c_uint32]
+        L.caster_primary_ids.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32)]
+        L.caster_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.caster_reset_stats.argtypes = [vp]
+        L.caster_iterations.argtypes = [vp]
+        L.caster_iterations.restype = C.c_uint32
+        L.caster_end.argtypes = [vp]
+        L.caster_end.restype = None
+        L.caster_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise CasterError(rc, lib().caster_last_error().decode(errors="replace"))
+
+
+class Scene:
+    """A parsed scene file plus its BVH (the reference's ``Scene`` + ``GlobalConfig``
+    after ``InitScene``, CUDA-PathTracer/tracer/parsescene.cpp:600-617)."""
+
+    def __init__(self, json_path):
+        h = C.c_void_p()
+        _check(lib().caster_scene_load(os.fspath(json_path).encode(), C.byref(h)))
+        self._h = h
+        info = SceneInfo()
+        _check(lib().caster_scene_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.width, self.height = info.width, info.height
+        self.integrator = info.integrator
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().caster_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Renderer:
+    """Device-side render state for one scene on one GPU."""
+
+    def __init__(self, scene, device=0, iters_in_flight=0):
+        h = C.c_void_p()
+        _check(lib().caster_begin(scene._h, int(device), int(iters_in_flight), C.byref(h)))
+        self._h = h
+        self.width, self.height = scene.width, scene.height
+        self.integrator = scene.integrator
+        self.device = device
+
+    def set_rows(self, y0, y1):
+        _check(lib().caster_set_rows(self._h, y0, y1))
+
+    def render(self, first_iter, n_iter=1, reset=False):
+        _check(lib().caster_render(self._h, first_iter, n_iter, 1 if reset else 0))
+
+    def render_async(self, first_iter, n_iter=1, reset=False):
+        _check(lib().caster_render_async(self._h, first_iter, n_iter, 1 if reset else 0))
+
+    def sync(self):
+        _check(lib().caster_sync(self._h))
+
+    def read_film(self, mode=0):
+        out = np.empty((self.height, self.width, 3), np.float32)
+        _check(lib().caster_read_film(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), mode))
+        return out
+
+    def read_film_device(self, device_ptr, mode=2):
+        _check(lib().caster_read_film_device(self._h, C.c_void_p(device_ptr), mode))
+
+    def film_add_device(self, device_ptr, n_iters):
+        _check(lib().caster_film_add_device(self._h, C.c_void_p(device_ptr), n_iters))
+
+    def primary_ids(self, it=1):
+        ids = np.empty((self.height, self.width), np.int32)
+        _check(lib().caster_primary_ids(self._h, it, ids.ctypes.data_as(C.POINTER(C.c_int32))))
+        return ids
+
+    def stats(self):
+        st = Stats()
+        _check(lib().caster_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def reset_stats(self):
+        _check(lib().caster_reset_stats(self._h))
+
+    @property
+    def iterations(self):
+        return lib().caster_iterations(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().caster_end(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- the reference's free-function boundary (pathtracer.h:8-10) ---------------
+_current = None
+
+
+def BeginRender(scene, width=None, height=None, epsilon=None, device=0, iters_in_flight=0):
+    """``BeginRender(scene, w, h, eps)``: uploads the scene.  ``width``, ``height`` and
+    ``epsilon`` are accepted for signature compatibility and must match the scene's own
+    (the reference always passes ``config.width/height/epsilon`` back in,
+    CudaRender.cpp:37)."""
+    global _current
+    if width is not None and (width != scene.width or height != scene.height):
+        raise CasterError(1, "BeginRender: width/height differ from the scene's")
+    if epsilon is not None and abs(epsilon - scene.info.epsilon) > 0:
+        raise CasterError(1, "BeginRender: epsilon differs from the scene's")
+    if _current is not None:
+        _current.close()
+    _current = Renderer(scene, device, iters_in_flight)
+    return _current
+
+
+def Render(scene, width, height, camera, iteration, reset, output=None):
+    """``Render(scene, w, h, camera, iter, reset, output)``: one sample per pixel for
+    iteration ``iteration`` (1-based), then ``output`` receives the tonemapped running
+    mean, as the reference's ``Output`` kernel writes it.  ``camera`` is ignored, as in
+    the reference (its upload is commented out, pathtracer.cu:2692)."""
+    if _current is None:
+        raise CasterError(1, "Render called before BeginRender")
+    _current.render(iteration, 1, reset)
+    img = _current.read_film(1)
+    if output is not None:
+        output[...] = img
+    return img
+
+
+def EndRender():
+    global _current
+    if _current is not None:
+        _current.close()
+        _current = None
+
+
+class CudaRender:
+    """Mirror of the reference's driver object (CudaRender.h:9-19), headless."""
+
+    _instance = None
+
+    @classmethod
+    def getInstance(cls):
+        if cls._instance is None:
+            cls._instance = cls()
+        return cls._instance
+
+    def __init__(self):
+        self.scene = None
+        self.renderer = None
+        self.iteration = 0
+        self.image = None
+
+    def InitCudaScene(self, file, device=0, iters_in_flight=1):
+        self.scene = Scene(file)
+        self.renderer = Renderer(self.scene, device, iters_in_flight)
+        self.iteration = 0
+
+    def renderImage(self):
+        self.iteration += 1  # the reference increments before rendering (CudaRender.cpp:49)
+        self.renderer.render(self.iteration, 1, False)
+        self.image = self.renderer.read_film(1)
+        return self.image
+
+    def GetRenderReverseImage(self):
+        return self.renderImage()[::-1].copy()
+
+    def GetConfig(self):
+        i = self.scene.info
+        return {"width": i.width, "height": i.height, "epsilon": i.epsilon}
+
+    def GetIteration(self):
+        return self.iteration
+
+    def SaveImage(self, path):
+        """Writes the last image as an 8-bit PNG, top row first (imageio.cpp:62-79)."""
+        from PIL import Image
+        a = (np.clip(self.image[::-1], 0.0, 1.0) * 255.0).astype(np.uint8)
+        Image.fromarray(a).save(path)

@@ -1,0 +1,113 @@
+// Device-side scene and path-state layout of the gfx950 wavefront renderer.
+//
+// The reference uploads its host structs verbatim (40-byte nodes, 176-byte
+// tagged-union primitives, 192-byte lights: CUDA-PathTracer/tracer/
+// pathtracer.cu:2554-2681) and binds them to __device__ globals with a <<<1,1>>>
+// kernel (pathtracer.cu:2519-2552).  Here everything a kernel needs is one
+// by-value parameter block of pointers into 16-byte-aligned float4 arrays laid
+// out for what each stage reads:
+//
+//   nodes   4 x float4 per inner node: both children's boxes and references
+//           (one 64-byte fetch decides two box tests; the reference fetches a
+//           node, tests its own box, then fetches each child)
+//   isect   3 x float4 per primitive: only what the ray/primitive test reads
+//   shade   8 x float4 per primitive: normals, uvs, tangents, indices; read
+//           once per accepted hit by the shade stage
+//   lights  6 x float4 per emissive triangle
+//   mats    6 x float4 per material
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace caster {
+
+constexpr int kNodeF4 = 4;
+constexpr int kIsectF4 = 3;
+constexpr int kShadeF4 = 8;
+constexpr int kLightF4 = 6;
+constexpr int kMatF4 = 6;
+constexpr int kMediumF4 = 3;
+
+constexpr int kRefEmpty = (int)0x80000000;  // child reference of an empty subtree
+
+// bits kept in the .w lane of the third isect float4
+constexpr uint32_t kPrimTypeMask = 3u;      // GT_TRIANGLE / GT_LINES / GT_SPHERE
+constexpr uint32_t kPrimLastInLeaf = 4u;    // leaf ranges end at the primitive carrying this bit
+
+struct DevCamera {
+  float pos[3], u[3], v[3], w[3];
+  float res_x, res_y, distance, apertureRadius, focalDistance;
+  float half_w, half_h, p2s_x, p2s_y, ratio;
+  int environment, medium, filmic;
+};
+
+struct DevInfinite {
+  int valid, w, h;
+  float radius;
+  float u[3], v[3], w_[3];
+  const float* data;  // 3 floats per texel, row-major
+};
+
+struct DevScene {
+  const float4* nodes;
+  const float4* isect;
+  const float4* shade;
+  const float4* lights;
+  const float4* mats;
+  const float4* media;
+  const float* light_cdf;
+  const uint32_t* tex_pool;   // packed rgba8 texels of every texture
+  const int* tex_info;        // per texture: offset, width, height
+  int n_prims, n_nodes, n_lights, n_cdf;
+  DevCamera cam;
+  DevInfinite inf;
+  float epsilon;
+  float g1, g2, g3;     // pbrt gamma(1..3), as the reference computes them
+  float box_scale;      // 1 + 2*gamma(3)
+  int integrator, maxDepth;
+  float maxDist;
+  int width, height;
+  int tiles_x, tiles_y;   // 8x8-pixel tiles: one tile per wavefront at generation
+  int slots_per_iter;     // tiles_x * tiles_y * 64
+};
+
+// Per-path state, structure of float4 arrays indexed by path slot.
+//   beta_rng  beta.xyz, minstd_rand state (uint bits)
+//   li_flags  Li.xyz, flags (uint bits, see kF*)
+//   pend_x    light-sampled direct term of the last shaded vertex (zeroed by
+//             the shadow stage when occluded), .w = |dot(wi, n)| of the BSDF-sampled probe
+//   pend_y    BSDF-sampled direct term: (fr.xyz, pdf) until the probe stage
+//             replaces it with the weighted contribution
+//   beta_prev throughput the two pending terms are to be multiplied with
+struct PathState {
+  float4* beta_rng;
+  float4* li_flags;
+  float4* pend_x;
+  float4* pend_y;
+  float4* beta_prev;
+};
+
+constexpr uint32_t kFBounceMask = 0xffffu;       // bounce counter
+constexpr uint32_t kFSpecular = 1u << 16;
+constexpr uint32_t kFPending = 1u << 17;
+constexpr uint32_t kFMediumShift = 20;           // bits 20..27: medium index + 1
+constexpr uint32_t kFMediumMask = 0xffu << kFMediumShift;
+
+// A compacted queue of rays: origin.xyz,tmin | dir.xyz,tmax | path slot, and,
+// for extension rays, the hit the extend stage found (t, prim id, b1, b2).
+struct RayQueue {
+  float4* o;
+  float4* d;
+  int* slot;
+  float4* hit;
+  uint32_t* count;
+};
+
+struct Stats {
+  unsigned long long rays[4];       // extension, shadow, MIS probe, transmittance segment
+  unsigned long long samples;
+  unsigned long long invalid;
+  unsigned long long stack_overflow;
+};
+
+}  // namespace caster

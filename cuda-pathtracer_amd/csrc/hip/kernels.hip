@@ -1,0 +1,1545 @@
+// gfx950 wavefront path tracer: generate / extend / shade / shadow / probe /
+// finish kernels over compacted ray queues.
+//
+// One path per lane, one 64-lane wavefront per workgroup.  A path's state
+// lives in SoA float4 arrays in HBM and travels between stages by slot index;
+// rays travel in compacted queues written with one atomic per wavefront.  The
+// closest-hit and any-hit walks keep a per-lane stack in LDS, lane-strided so
+// that a push or pop is one conflict-free ds access.
+//
+// What each stage computes follows the reference integrators
+// (CUDA-PathTracer/tracer/pathtracer.cu:822-1228) exactly, sample by sample:
+// the same per-pixel minstd_rand stream, the same draw order, the same
+// arithmetic in the same order (built with -ffp-contract=off against
+// fpspec.h), so an image is a pure function of (scene, pixel, iteration).
+#include <hip/hip_runtime.h>
+
+#include "../fpspec.h"
+#include "device_scene.h"
+
+namespace caster {
+
+constexpr int kWave = 64;
+constexpr int kStackDepth = 32;
+
+// ------------------------------------------------------------------ vectors
+struct V3 { float x, y, z; };
+struct V2 { float x, y; };
+__device__ inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ inline V3 v3(float4 f) { return V3{f.x, f.y, f.z}; }
+__device__ inline V3 v3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ inline V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+__device__ inline V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ inline V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ inline V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+__device__ inline V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+__device__ inline V3 operator+(V3 a, float s) { return V3{a.x + s, a.y + s, a.z + s}; }
+__device__ inline V3 operator-(V3 a, float s) { return V3{a.x - s, a.y - s, a.z - s}; }
+__device__ inline V3 operator-(float s, V3 a) { return V3{s - a.x, s - a.y, s - a.z}; }
+__device__ inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline V3 cross(V3 a, V3 b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ inline float length(V3 v) { return sqrtf(dot(v, v)); }
+__device__ inline V3 normalize(V3 v) { return v * fps::rsqrt_(dot(v, v)); }
+__device__ inline V3 vabs(V3 v) { return V3{fabsf(v.x), fabsf(v.y), fabsf(v.z)}; }
+__device__ inline float maxcomp(V3 a) { return fps::fmax_(fps::fmax_(a.x, a.y), a.z); }
+__device__ inline bool is_black(V3 c) { return c.x == 0 && c.y == 0 && c.z == 0; }
+__device__ inline bool isinf_(float v) { return v == INFINITY || v == -INFINITY; }
+__device__ inline bool has_nan(V3 c) { return c.x != c.x || c.y != c.y || c.z != c.z; }
+__device__ inline bool has_inf(V3 c) { return isinf_(c.x) || isinf_(c.y) || isinf_(c.z); }
+__device__ inline float4 f4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ inline float4 f4(V3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
+
+// common.h:17-22 of the reference
+constexpr float PI = 3.14159265358f;
+constexpr float TWOPI = 6.28318530716f;
+constexpr float ONE_OVER_PI = 0.3183098861847f;
+constexpr float ONE_OVER_TWO_PI = 0.1591549430923f;
+constexpr float ONE_OVER_FOUR_PI = 0.0795774715461f;
+
+// ---------------------------------------------------------------------- RNG
+// thrust::default_random_engine (minstd_rand: x <- 48271 x mod 2^31-1) seeded
+// with WangHash(pixel)+WangHash(iter) (pathtracer.cu:830, common.h:200-209).
+__device__ inline uint32_t wang_hash(uint32_t seed) {
+  seed = (seed ^ 61u) ^ (seed >> 16);
+  seed = seed + (seed << 3);
+  seed = seed ^ (seed >> 4);
+  seed = seed * 0x27d4eb2du;
+  seed = seed ^ (seed >> 15);
+  return seed;
+}
+__device__ inline uint32_t rng_seed(uint32_t pixel, uint32_t iter) {
+  uint32_t s = wang_hash(pixel) + wang_hash(iter);
+  uint32_t x = s % 2147483647u;
+  return x == 0 ? 1u : x;
+}
+__device__ inline float rng_uniform(uint32_t& x) {
+  // 2^31-1 is a Mersenne prime: fold the 47-bit product instead of dividing.
+  uint64_t p = (uint64_t)x * 48271u;
+  uint32_t r = (uint32_t)(p & 0x7fffffffu) + (uint32_t)(p >> 31);
+  if (r >= 2147483647u) r -= 2147483647u;
+  x = r;
+  float f = (float)(r - 1u);
+  f /= 2147483648.0f;  // 1.0f + float(2147483645)
+  return f;
+}
+
+// ---------------------------------------------------------- sampling warps
+__device__ inline V3 cosine_hemisphere(float u1, float u2, float& pdf) {  // Sampling.h:31-43
+  float sintheta = sqrtf(u1);
+  float costheta = sqrtf(1.f - u1);
+  float phi = TWOPI * u2;
+  float cosphi = fps::cos_(phi);
+  float sinphi = fps::sin_(phi);
+  pdf = fabsf(costheta) * ONE_OVER_PI;
+  return v3(sintheta * cosphi, sintheta * sinphi, costheta);
+}
+__device__ inline V3 uniform_sphere(float u1, float u2, float& pdf) {  // Sampling.h:4-15
+  float costheta = 1.f - 2.f * u1;
+  float sintheta = sqrtf(1.f - costheta * costheta);
+  float phi = TWOPI * u2;
+  float cosphi = fps::cos_(phi);
+  float sinphi = fps::sin_(phi);
+  pdf = ONE_OVER_FOUR_PI;
+  return v3(sintheta * cosphi, sintheta * sinphi, costheta);
+}
+__device__ inline V3 to_world(V3 d, V3 u, V3 v, V3 w) { return d.x * u + d.y * v + d.z * w; }
+__device__ inline void make_coordinate(V3 n, V3& u, V3& w) {  // common.h:116-129
+  if (fabsf(n.x) > fabsf(n.y)) {
+    float invLen = 1.0f / sqrtf(n.x * n.x + n.z * n.z);
+    w = v3(n.z * invLen, 0.0f, -n.x * invLen);
+  } else {
+    float invLen = 1.0f / sqrtf(n.y * n.y + n.z * n.z);
+    w = v3(0.0f, n.z * invLen, -n.y * invLen);
+  }
+  u = cross(w, n);
+}
+
+// ------------------------------------------------------------- primary rays
+// Camera::GeneratePrimaryRay (Camera.h:45-85)
+__device__ inline void primary_ray(const DevCamera& c, float x, float y, float a1, float a2, V3& orig, V3& dir) {
+  V3 cu = v3(c.u), cv = v3(c.v), cw = v3(c.w);
+  orig = v3(c.pos);
+  if (c.environment) {
+    float theta = PI * (1.f - y / c.res_y);
+    float phi = TWOPI * (1.f - x / c.res_x);
+    V3 l = v3(fps::sin_(theta) * fps::cos_(phi), fps::cos_(theta), fps::sin_(theta) * fps::sin_(phi));
+    dir = l.x * cu + l.y * cv - l.z * cw;
+    return;
+  }
+  float xx = x * c.p2s_x - c.half_w;
+  float yy = y * c.p2s_y - c.half_h;
+  if (c.apertureRadius > 0.00001f) {
+    // UniformSampleDisk (Sampling.h:59-67)
+    float r = sqrtf(a1);
+    float phi = TWOPI * a2;
+    float ax = (r * fps::cos_(phi)) * c.apertureRadius;
+    float ay = (r * fps::sin_(phi)) * c.apertureRadius;
+    float focal_x = c.ratio * xx;
+    float focal_y = c.ratio * yy;
+    V3 aperture = v3(ax, ay, 0);
+    V3 focal = v3(focal_x, focal_y, -c.focalDistance);
+    V3 l = focal - aperture;
+    dir = l.x * cu + l.y * cv + l.z * cw;
+    orig = orig + (aperture.x * cu + aperture.y * cv);
+  } else {
+    dir = xx * cu + yy * cv + -c.distance * cw;
+  }
+  dir = normalize(dir);
+}
+
+// Path slot <-> pixel: slots of one iteration are laid out tile by tile so a
+// wavefront's 64 primary rays cover an 8x8 pixel block.
+__device__ inline bool slot_pixel(const DevScene& S, uint32_t local, uint32_t& px, uint32_t& py) {
+  uint32_t tile = local >> 6, in = local & 63u;
+  uint32_t tx = tile % (uint32_t)S.tiles_x, ty = tile / (uint32_t)S.tiles_x;
+  px = tx * 8 + (in & 7u);
+  py = ty * 8 + (in >> 3);
+  return px < (uint32_t)S.width && py < (uint32_t)S.height;
+}
+__device__ inline uint32_t pixel_slot(const DevScene& S, uint32_t px, uint32_t py) {
+  uint32_t tile = (py >> 3) * (uint32_t)S.tiles_x + (px >> 3);
+  return (tile << 6) | ((py & 7u) << 3) | (px & 7u);
+}
+
+// Append one item per active lane of this wavefront to a queue: one atomic
+// per wavefront, lane offsets from the ballot.
+__device__ inline uint32_t queue_reserve(uint32_t* counter, bool want) {
+  unsigned long long mask = __ballot(want);
+  if (mask == 0) return 0;
+  uint32_t n = (uint32_t)__popcll(mask);
+  uint32_t lane = threadIdx.x & 63u;
+  uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  uint32_t base = 0;
+  int leader = __ffsll((long long)mask) - 1;
+  if ((int)lane == leader) base = atomicAdd(counter, n);
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  return base + prefix;
+}
+
+// --------------------------------------------------------------- traversal
+// Slab test of the reference (bbox.h:75-98): tFar widened by 1+2*gamma(3),
+// rejected when behind the ray, empty, or beyond the current tmax; tmin is
+// not consulted.  Returns tNear through `tn`.
+__device__ inline bool box_test(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float scale, float& tn) {
+  float txNear = (lo.x - o.x) * inv.x;
+  float txFar = (hi.x - o.x) * inv.x;
+  float tyNear = (lo.y - o.y) * inv.y;
+  float tyFar = (hi.y - o.y) * inv.y;
+  float tzNear = (lo.z - o.z) * inv.z;
+  float tzFar = (hi.z - o.z) * inv.z;
+  using fps::fmax_;
+  using fps::fmin_;
+  float tNear = fmax_(fmax_(fmin_(txNear, txFar), fmin_(tyNear, tyFar)), fmin_(tzNear, tzFar));
+  float tFar = fmin_(fmin_(fmax_(txNear, txFar), fmax_(tyNear, tyFar)), fmax_(tzNear, tzFar));
+  tFar *= scale;
+  tn = tNear;
+  if (tFar <= 0.00001f) return false;
+  if (tNear > tFar) return false;
+  if (tNear > tmax) return false;
+  return true;
+}
+
+struct Hit {
+  float t;
+  int prim;
+  float b1, b2;  // triangle barycentrics; line: s, d2
+};
+
+// Ray/primitive tests.  Each returns the candidate parameter in `t`; the
+// caller applies the closest-hit rule.  Triangle: Triangle.h:87-118 with the
+// edge vectors and coordinate maxima precomputed per primitive (the same
+// float operations, done once on the host).  Sphere: sphere.h:24-66.  Line:
+// line.h:33-72.
+__device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, float tmax,
+                                 float& t, float& ob1, float& ob2, bool& last) {
+  const float4* rec = S.isect + (size_t)i * kIsectF4;
+  float4 a = rec[0], b = rec[1], c = rec[2];
+  uint32_t bits = __float_as_uint(c.w);
+  last = (bits & kPrimLastInLeaf) != 0;
+  uint32_t type = bits & kPrimTypeMask;
+  if (type == 0u) {
+    V3 p1 = v3(a), e1 = v3(b), e2 = v3(c);
+    float maxE = a.w, maxP1 = b.w;
+    V3 s1 = cross(d, e2);
+    float divisor = dot(s1, e1);
+    if (fabsf(divisor) < 1e-8f) return false;
+    float inv = 1.0f / divisor;
+    V3 s = o - p1;
+    float b1 = dot(s, s1) * inv;
+    if (b1 < 0.0f || b1 > 1.0f) return false;
+    V3 s2 = cross(s, e1);
+    float b2 = dot(d, s2) * inv;
+    if (b2 < 0.0f || b1 + b2 > 1.0f) return false;
+    float deltaE = S.g1 * maxE;
+    float deltaS1 = 2 * (S.g2 * maxD * maxE + deltaE * maxD);
+    float deltaS = S.g1 * maxP1;
+    float maxS = maxcomp(vabs(s));
+    float maxS1 = maxcomp(vabs(s1));
+    float deltaS2 = 2 * (S.g2 * maxS * maxS1 + deltaS * maxS1 + deltaS1 * maxS);
+    float maxS2 = maxcomp(vabs(s2));
+    float deltaT = 2 * (S.g2 * maxE * maxS2 + deltaS2 * maxE + deltaE * maxS2) * fabsf(inv);
+    float tt = dot(e2, s2) * inv;
+    if (tt < tmin + deltaT || tt > tmax) return false;
+    t = tt; ob1 = b1; ob2 = b2;
+    return true;
+  }
+  if (type == 2u) {
+    V3 op = o - v3(a);
+    float radius = a.w;
+    float B = dot(op, d);
+    float C = dot(op, op) - radius * radius;
+    float delta = B * B - C;
+    if (delta < 0.f) return false;
+    float sq = sqrtf(delta);
+    float t1 = -B - sq;
+    float t2 = -B + sq;
+    if (t1 < 0.f && t2 < 0.f) return false;
+    if (t1 < 0.f || t2 < 0.f) {
+      float tt1 = t1, tt2 = t2;
+      t1 = tt1 < 0.f ? tt2 : tt1;
+      t2 = tt1 < 0.f ? tt1 : tt2;
+    } else if (t1 > t2) {
+      float tmp = t2; t2 = t1; t1 = tmp;
+    }
+    if (t1 > tmax) return false;
+    float th;
+    if (t1 > tmin) th = t1;
+    else if (t2 > 0.f) th = t2;
+    else return false;
+    if (th > tmax) return false;
+    t = th; ob1 = 0.f; ob2 = 0.f;
+    return true;
+  }
+  {
+    V3 p0 = v3(a), p1 = v3(b);
+    V3 u = d;
+    V3 v = p1 - p0;
+    V3 w = o - p0;
+    float aa = dot(u, u), bb = dot(u, v), cc = dot(v, v), dd = dot(u, w), ee = dot(v, w);
+    float det = aa * cc - bb * bb;
+    if (det == 0) return false;
+    float tt = (bb * ee - cc * dd) / det;
+    float s = (aa * ee - bb * dd) / det;
+    if (tt < tmin || tt > tmax) return false;
+    s = fps::clamp_(s, 0.f, 1.f);
+    V3 pr = o + d * tt;
+    V3 pl = p0 + (p1 - p0) * s;
+    V3 prl = pr - pl;
+    float d2 = dot(prl, prl);
+    float r = a.w * (1 - s) + b.w * s;
+    if (d2 > r * r) return false;
+    t = tt; ob1 = s; ob2 = d2;
+    return true;
+  }
+}
+
+// Closest-hit (ANY=false) or any-hit (ANY=true) walk.  Children are visited
+// nearest first; a deferred child carries its entry distance so that it is
+// dropped at pop time once a closer hit is known, which is the test the
+// reference makes when it reaches that node (pathtracer.cu:231-232).  Among
+// hits at equal distance the higher primitive index wins, as in the
+// reference's in-order leaf scan with its `t <= tmax` acceptance.
+template <bool ANY>
+__device__ inline bool traverse(const DevScene& S, V3 o, V3 d, float tmin, float tmax, Hit& hit,
+                                int (*s_ref)[kWave], float (*s_tn)[kWave], unsigned long long* overflow) {
+  const uint32_t lane = threadIdx.x & 63u;
+  V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  float maxD = maxcomp(vabs(d));
+  hit.prim = -1;
+  hit.t = tmax;
+  hit.b1 = hit.b2 = 0.f;
+  if (S.n_nodes == 0) return false;
+  int sp = 0;
+  int cur = 0;
+  for (;;) {
+    if (cur >= 0) {
+      const float4* n = S.nodes + (size_t)cur * kNodeF4;
+      float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+      float tn0, tn1;
+      bool h0 = box_test(v3(n0), v3(n1), o, inv, hit.t, S.box_scale, tn0);
+      bool h1 = box_test(v3(n2), v3(n3), o, inv, hit.t, S.box_scale, tn1);
+      int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
+      if (h0 && h1) {
+        int nearc = c0, farc = c1;
+        float fart = tn1;
+        if (tn1 < tn0) { nearc = c1; farc = c0; fart = tn0; }
+        if (sp < kStackDepth) {
+          s_ref[sp][lane] = farc;
+          s_tn[sp][lane] = fart;
+          ++sp;
+        } else {
+          atomicAdd(overflow, 1ull);
+        }
+        cur = nearc;
+        continue;
+      }
+      if (h0) { cur = c0; continue; }
+      if (h1) { cur = c1; continue; }
+    } else if (cur != kRefEmpty) {
+      int i = ~cur;
+      bool last;
+      do {
+        float t, b1, b2;
+        if (prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last)) {
+          if (ANY) return true;
+          // t <= hit.t here; at equal distance the higher index wins
+          if (t < hit.t || i > hit.prim) { hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2; }
+        }
+        ++i;
+      } while (!last);
+    }
+    // pop
+    for (;;) {
+      if (sp == 0) return hit.prim >= 0;
+      --sp;
+      cur = s_ref[sp][lane];
+      if (!(s_tn[sp][lane] > hit.t)) break;
+    }
+  }
+}
+
+// ----------------------------------------------------------------- kernels
+struct LaunchCtx {
+  DevScene S;
+  PathState P;
+  Stats* stats;
+};
+
+// Camera samples for iterations [first_iter, first_iter + n_iter): seeds the
+// RNG, draws the four camera numbers (pathtracer.cu:881-890), writes the
+// extension ray and fresh path state.  Queue index == path slot here.
+__global__ __launch_bounds__(kWave) void k_generate(LaunchCtx L, RayQueue q, uint32_t first_iter, uint32_t n_iter,
+                                                    int y0, int y1) {
+  const DevScene& S = L.S;
+  uint32_t total = (uint32_t)S.slots_per_iter * n_iter;
+  for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < total; idx += gridDim.x * kWave) {
+    uint32_t k = idx / (uint32_t)S.slots_per_iter;
+    uint32_t local = idx - k * (uint32_t)S.slots_per_iter;
+    uint32_t px, py;
+    bool live = slot_pixel(S, local, px, py) && (int)py >= y0 && (int)py < y1;
+    uint32_t iter = first_iter + k;
+    float4 o4 = make_float4(0, 0, 0, 0), d4 = make_float4(0, 0, 1, -1.f);
+    uint32_t rng = 1u;
+    if (live) {
+      uint32_t pixel = px + py * (uint32_t)S.width;
+      rng = rng_seed(pixel, iter);
+      float offsetx = rng_uniform(rng) - 0.5f;
+      float offsety = rng_uniform(rng) - 0.5f;
+      float a1 = rng_uniform(rng);
+      float a2 = rng_uniform(rng);
+      V3 orig, dir;
+      primary_ray(S.cam, px + offsetx, py + offsety, a1, a2, orig, dir);
+      o4 = f4(orig, S.epsilon);
+      d4 = f4(dir, INFINITY);
+    }
+    uint32_t flags = 0;
+    if (S.integrator == 2 /*IT_VPT*/) flags |= (uint32_t)(S.cam.medium + 1) << kFMediumShift;
+    q.o[idx] = o4;
+    q.d[idx] = d4;  // tmax < 0 marks a slot outside the image: extend skips it
+    q.slot[idx] = (int)idx;
+    L.P.beta_rng[idx] = f4(v3(1.f, 1.f, 1.f), rng);
+    L.P.li_flags[idx] = f4(v3(0.f, 0.f, 0.f), flags);
+    L.P.beta_prev[idx] = make_float4(0, 0, 0, 0);
+  }
+}
+
+__global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
+
+// Closest hit for every ray of a queue; the hit goes back into the queue
+// entry (coalesced), to be consumed by the shade stage.
+__global__ __launch_bounds__(kWave) void k_extend(LaunchCtx L, RayQueue q) {
+  __shared__ int s_ref[kStackDepth][kWave];
+  __shared__ float s_tn[kStackDepth][kWave];
+  const uint32_t count = *q.count;
+  for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
+    float4 o4 = q.o[idx], d4 = q.d[idx];
+    Hit h;
+    h.t = d4.w; h.prim = -1; h.b1 = h.b2 = 0.f;
+    if (d4.w >= 0.f) traverse<false>(L.S, v3(o4), v3(d4), o4.w, d4.w, h, s_ref, s_tn, &L.stats->stack_overflow);
+    q.hit[idx] = make_float4(h.t, __int_as_float(h.prim), h.b1, h.b2);
+  }
+}
+
+// Any-hit for the light-sample rays: an occluded ray clears the pending
+// light-sampled term of its path.
+__global__ __launch_bounds__(kWave) void k_shadow(LaunchCtx L, RayQueue q) {
+  __shared__ int s_ref[kStackDepth][kWave];
+  __shared__ float s_tn[kStackDepth][kWave];
+  const uint32_t count = *q.count;
+  for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
+    float4 o4 = q.o[idx], d4 = q.d[idx];
+    Hit h;
+    bool occluded = traverse<true>(L.S, v3(o4), v3(d4), o4.w, d4.w, h, s_ref, s_tn, &L.stats->stack_overflow);
+    if (occluded) {
+      int slot = q.slot[idx];
+      float4 px = L.P.pend_x[slot];
+      px.x = 0.f; px.y = 0.f; px.z = 0.f;
+      L.P.pend_x[slot] = px;
+    }
+  }
+}
+
+// -------------------------------------------------------------- shading data
+struct Isect {
+  V3 pos, n, dpdu;
+  V2 uv;
+  int mat, light, med_in, med_out;
+};
+
+// Rebuilds the reference's Intersection record from (ray, hit): Triangle.h:
+// 121-141 (shading normal = interpolated normal, tangent re-orthogonalised),
+// sphere.h:69-88, line.h:74-84.
+__device__ inline void load_isect(const DevScene& S, V3 o, V3 d, const Hit& h, Isect& is) {
+  const float4* sh = S.shade + (size_t)h.prim * kShadeF4;
+  const float4* ir = S.isect + (size_t)h.prim * kIsectF4;
+  uint32_t type = __float_as_uint(ir[2].w) & kPrimTypeMask;
+  float4 ids = sh[6];
+  is.mat = __float_as_int(ids.x);
+  is.light = __float_as_int(ids.y);
+  is.med_in = __float_as_int(ids.z);
+  is.med_out = __float_as_int(ids.w);
+  is.pos = o + h.t * d;
+  if (type == 0u) {
+    float4 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3], s4 = sh[4], s5 = sh[5];
+    float b1 = h.b1, b2 = h.b2;
+    V3 ns = normalize(v3(s0) * (1.f - b1 - b2) + v3(s1) * b1 + v3(s2) * b2);
+    V3 ss = normalize(v3(s3) * (1.f - b1 - b2) + v3(s4) * b1 + v3(s5) * b2);
+    V3 ts = cross(ss, ns);
+    if (length(ts) > 0.f) {
+      ts = normalize(ts);
+      ss = cross(ts, ns);
+    }
+    is.n = ns;
+    is.dpdu = ss;
+    float b0 = 1.f - b1 - b2;
+    is.uv = V2{s0.w * b0 + s2.w * b1 + s4.w * b2, s1.w * b0 + s3.w * b1 + s5.w * b2};
+  } else if (type == 2u) {
+    float4 c = sh[0];
+    is.n = normalize(is.pos - v3(c));
+    V3 normal = is.n;
+    float costheta = dot(normal, v3(0.f, 1.f, 0.f));
+    float v = fps::acos_(costheta) * ONE_OVER_PI;
+    float cosphi = dot(v3(1.f, 0.f, 0.f), v3(normal.x, 0.f, normal.z));
+    float phi = fps::acos_(cosphi);
+    phi = normal.z > 0.f ? TWOPI - phi : phi;
+    float u = phi * ONE_OVER_TWO_PI;
+    is.dpdu = normalize(v3(-TWOPI * is.pos.y, TWOPI * is.pos.x, 0));
+    is.uv = V2{u, v};
+    is.light = -1;
+  } else {
+    float4 a = sh[0], b = sh[1];
+    float s = h.b1, d2 = h.b2;
+    float r = a.w * (1 - s) + b.w * s;
+    is.n = -d;
+    is.uv = V2{s, sqrtf(d2) / r};
+    V3 dpdu, dpdv;
+    make_coordinate(is.n, dpdu, dpdv);
+    is.dpdu = dpdu;
+    is.light = -1;
+    is.med_in = -1;
+    is.med_out = -1;
+  }
+}
+
+struct Mat {
+  int type, tex;
+  float alphaU, alphaV, insideIOR, outsideIOR;
+  V3 k, eta, diffuse, specular;
+};
+__device__ inline void load_mat(const DevScene& S, int idx, Mat& m) {
+  const float4* r = S.mats + (size_t)idx * kMatF4;
+  float4 a = r[0], b = r[1];
+  m.type = __float_as_int(a.x); m.alphaU = a.y; m.alphaV = a.z; m.insideIOR = a.w;
+  m.outsideIOR = b.x; m.tex = __float_as_int(b.y);
+  m.k = v3(r[2]); m.eta = v3(r[3]); m.diffuse = v3(r[4]); m.specular = v3(r[5]);
+}
+
+// getTexel / GetTexel (pathtracer.cu:333-368)
+__device__ inline float4 texel(const uint32_t* pool, int w, int h, int x, int y) {
+  float inv = 1.f / 255.f;
+  float rx = (float)(x - (x / w) * w);
+  float ry = (float)(y - (y / h) * h);
+  x = fps::f2i_((rx < 0) ? rx + w : rx);
+  y = fps::f2i_((ry < 0) ? ry + h : ry);
+  if (x < 0) x = 0;
+  if (x > w - 1) x = w - 1;
+  if (y < 0) y = 0;
+  if (y > h - 1) y = h - 1;
+  uint32_t c = pool[(size_t)y * w + x];
+  return make_float4((c & 255u) * inv, ((c >> 8) & 255u) * inv, ((c >> 16) & 255u) * inv, (c >> 24) * inv);
+}
+__device__ inline float4 sc4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ inline float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ inline V3 albedo(const DevScene& S, const Mat& m, V2 uv) {
+  if (m.tex == -1) return m.diffuse;
+  const int* info = S.tex_info + 3 * m.tex;
+  const uint32_t* pool = S.tex_pool + info[0];
+  int w = info[1], h = info[2];
+  float xx = w * uv.x;
+  float yy = h * uv.y;
+  int x = fps::f2i_(floorf(xx));
+  int y = fps::f2i_(floorf(yy));
+  float dx = fabsf(xx - x);
+  float dy = fabsf(yy - y);
+  float4 c00 = texel(pool, w, h, x, y), c10 = texel(pool, w, h, x + 1, y);
+  float4 c01 = texel(pool, w, h, x, y + 1), c11 = texel(pool, w, h, x + 1, y + 1);
+  float4 r = add4(sc4(1 - dy, add4(sc4(1 - dx, c00), sc4(dx, c10))), sc4(dy, add4(sc4(1 - dx, c01), sc4(dx, c11))));
+  return v3(r.x, r.y, r.z);
+}
+
+// --------------------------------------------------------------------- BSDFs
+// pathtracer.cu:45-178
+__device__ inline V3 spherical_dir(float s, float c, float phi) { return v3(s * fps::cos_(phi), s * fps::sin_(phi), c); }
+__device__ inline float dielectric_fresnel(float cosi, float cost, float etai, float etat) {
+  float Rparl = (etat * cosi - etai * cost) / (etat * cosi + etai * cost);
+  float Rperp = (etai * cosi - etat * cost) / (etai * cosi + etat * cost);
+  return (Rparl * Rparl + Rperp * Rperp) * 0.5f;
+}
+__device__ inline V3 conduct_fresnel(float cosi, V3 eta, V3 k) {
+  V3 tmp = (eta * eta + k * k) * cosi * cosi;
+  V3 Rparl2 = (tmp - eta * cosi * 2.f + 1.f) / (tmp + eta * cosi * 2.f + 1.f);
+  V3 tmp_f = (eta * eta + k * k);
+  V3 Rperp2 = (tmp_f - eta * cosi * 2.f + cosi * cosi) / (tmp_f + eta * cosi * 2.f + cosi * cosi);
+  return (Rparl2 + Rperp2) * 0.5f;
+}
+__device__ inline float ggx_d(V3 wh, V3 normal, V3 dpdu, float alphaU, float alphaV) {
+  float costheta = dot(wh, normal);
+  if (costheta <= 0.f) return 0.f;
+  costheta = fps::clamp_(costheta, 0.f, 1.f);
+  float cos2Theta = costheta * costheta;
+  float sin2Theta = 1.f - cos2Theta;
+  float cos4Theta = cos2Theta * cos2Theta;
+  float tantheta2 = sin2Theta / cos2Theta;
+  V3 dir = normalize(wh - costheta * normal);
+  float cosphi = dot(dir, dpdu);
+  float e = tantheta2 * (cosphi * cosphi / (alphaU * alphaU) + (1.f - cosphi) / (alphaV * alphaV));
+  return 1.f / (PI * alphaU * alphaV * cos4Theta * (1 + e) * (1 + e));
+}
+__device__ inline float smith_g(V3 w, V3 normal, V3 wh, V3 dpdu, float alphaU, float alphaV) {
+  float wdn = dot(w, normal);
+  if (wdn * dot(w, wh) < 0.f) return 0.f;
+  float sinTheta = sqrtf(fps::clamp_(1.f - wdn * wdn, 0.f, 1.f));
+  float tanTheta = sinTheta / wdn;
+  if (isinf_(tanTheta)) return 0.f;
+  V3 dir = normalize(w - wdn * normal);
+  float cosPhi = dot(dir, dpdu);
+  float cos2Phi = cosPhi * cosPhi;
+  float sin2Phi = 1.f - cos2Phi;
+  float alpha2 = cos2Phi * (alphaU * alphaU) + sin2Phi * (alphaV * alphaV);
+  float alpha2Tan2Theta = alpha2 * tanTheta * tanTheta;
+  return 2.f / (1.f + sqrtf(1 + alpha2Tan2Theta));
+}
+__device__ inline float ggx_g(V3 wo, V3 wi, V3 normal, V3 wh, V3 dpdu, float aU, float aV) {
+  return smith_g(wo, normal, wh, dpdu, aU, aV) * smith_g(wi, normal, wh, dpdu, aU, aV);
+}
+__device__ inline V3 sample_ggx(float alphaU, float alphaV, float u1, float u2) {
+  if (alphaU == alphaV) {
+    float costheta = sqrtf((1.f - u1) / (u1 * (alphaU * alphaV - 1.f) + 1.f));
+    float sintheta = sqrtf(1.f - costheta * costheta);
+    float phi = TWOPI * u2;
+    return spherical_dir(sintheta, costheta, phi);
+  }
+  float phi = fps::atan_(alphaV / alphaU * fps::tan_(TWOPI * u2 + .5f * PI));
+  if (u2 > .5f) phi += PI;
+  float sinphi = fps::sin_(phi), cosphi = fps::cos_(phi);
+  const float alphaU2 = alphaU * alphaU;
+  const float alpha2 = 1.0f / (cosphi * cosphi / alphaU2 + sinphi * sinphi / alphaU2);
+  float tanTheta2 = alpha2 * u1 / (1.f - u1);
+  float costheta = 1 / sqrtf(1 + tanTheta2);
+  float sintheta = sqrtf(fps::fmax_(0.f, 1.f - costheta * costheta));
+  return spherical_dir(sintheta, costheta, phi);
+}
+__device__ inline V3 reflect(V3 in, V3 nor) { return 2.f * dot(in, nor) * nor - in; }
+__device__ inline V3 refract(V3 in, V3 nor, float etai, float etat) {
+  float cosi = dot(in, nor);
+  bool enter = cosi > 0;
+  if (!enter) { float t = etai; etai = etat; etat = t; }
+  float eta = etai / etat;
+  float sini2 = 1.f - cosi * cosi;
+  float sint2 = sini2 * eta * eta;
+  float cost = sqrtf(1.f - sint2);
+  return normalize((nor * cosi - in) * eta + (enter ? -cost : cost) * nor);
+}
+__device__ inline float pow5(float v) { return (v * v) * (v * v) * v; }
+__device__ inline V3 schlick(V3 Rs, float c) { return Rs + pow5(1.f - c) * (1 - Rs); }
+__device__ inline float power_heuristic(float fPdf, float gPdf) {
+  float f = 1 * fPdf, g = 1 * gPdf;
+  return (f * f) / (f * f + g * g);
+}
+__device__ inline float luminance(V3 c) { return dot(c, v3(0.212671f, 0.715160f, 0.072169f)); }
+__device__ inline bool same_hemisphere(V3 in, V3 out, V3 nor) { return dot(in, nor) * dot(out, nor) > 0; }
+__device__ inline bool is_delta(int t) { return t == 1 || t == 2; }  // mirror, dielectric
+
+// SampleBSDF (pathtracer.cu:500-698), radiance transport.
+__device__ void sample_bsdf(const DevScene& S, const Mat& m, V3 in, V3 nor, V2 uv, V3 dpdu, V3 u, V3& out, V3& fr,
+                            float& pdf) {
+  switch (m.type) {
+    case 0: {  // lambertian
+      V3 n = nor;
+      if (dot(nor, in) < 0) n = -n;
+      out = cosine_hemisphere(u.x, u.y, pdf);
+      V3 uu = dpdu, ww = cross(uu, n);
+      out = to_world(out, uu, ww, n);
+      fr = albedo(S, m, uv) * ONE_OVER_PI;
+      break;
+    }
+    case 1:  // mirror
+      out = reflect(in, nor);
+      fr = m.specular / fabsf(dot(out, nor));
+      pdf = 1.f;
+      break;
+    case 2: {  // dielectric
+      V3 wi = -in;
+      V3 normal = nor;
+      float ei = m.outsideIOR, et = m.insideIOR;
+      float cosi = dot(wi, normal);
+      if (cosi > 0) { float t = et; et = ei; ei = t; }
+      float eta = ei / et;
+      float sint2 = eta * eta * (1.f - cosi * cosi);
+      float cost = sqrtf(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
+      V3 rdir = reflect(-wi, normal);
+      V3 tdir = refract(in, nor, m.outsideIOR, m.insideIOR);
+      if (sint2 > 1.f) {
+        out = rdir;
+        fr = m.specular / fabsf(dot(out, normal));
+        pdf = 1.f;
+        return;
+      }
+      float fresnel = dielectric_fresnel(fabsf(cost), fabsf(cosi), et, ei);
+      if (u.x > fresnel) {
+        out = tdir;
+        fr = m.specular / fabsf(dot(out, normal)) * (1.f - fresnel);
+        fr = fr * (eta * eta);
+        pdf = 1.f - fresnel;
+      } else {
+        out = rdir;
+        fr = m.specular / fabsf(dot(out, normal)) * fresnel;
+        pdf = fresnel;
+      }
+      break;
+    }
+    case 4: {  // rough conductor
+      V3 n = nor;
+      if (dot(nor, in) < 0) n = -n;
+      V3 wh = sample_ggx(m.alphaU, m.alphaV, u.x, u.y);
+      V3 uu = dpdu, ww = cross(uu, n);
+      wh = to_world(wh, uu, ww, n);
+      out = reflect(in, wh);
+      if (!same_hemisphere(in, out, nor)) { fr = v3(0, 0, 0); pdf = 0.f; return; }
+      float cosi = dot(out, wh);
+      V3 F = conduct_fresnel(fabsf(cosi), m.eta, m.k);
+      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
+      float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
+      fr = m.specular * F * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
+      pdf = D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(in, wh)));
+      break;
+    }
+    case 5: {  // substrate
+      V3 n = nor;
+      if (dot(nor, in) < 0) n = -n;
+      if (u.x < 0.5f) {
+        u.x = fps::fmin_(2.f * u.x, 0x1.fffffep-1f);
+        out = cosine_hemisphere(u.x, u.y, pdf);
+        V3 uu = dpdu, ww = cross(uu, n);
+        out = to_world(out, uu, ww, n);
+      } else {
+        u.x = fps::fmin_(2 * (u.x - 0.5f), 0x1.fffffep-1f);
+        V3 wh = sample_ggx(m.alphaU, m.alphaV, u.x, u.y);
+        V3 uu = dpdu, ww = cross(uu, n);
+        wh = to_world(wh, uu, ww, n);
+        out = reflect(in, wh);
+      }
+      if (!same_hemisphere(in, out, n)) { fr = v3(0, 0, 0); pdf = 0.f; return; }
+      float cosThetaWo = fabsf(dot(in, n));
+      float cosThetaWi = fabsf(dot(out, n));
+      V3 Rd = albedo(S, m, uv);
+      V3 Rs = m.specular;
+      V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) * (1 - pow5(1 - .5f * cosThetaWi)) *
+                   (1 - pow5(1 - .5f * cosThetaWo));
+      V3 wh = normalize(in + out);
+      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
+      float mx = cosThetaWi > cosThetaWo ? cosThetaWi : cosThetaWo;
+      V3 specular = D / (4.f * fabsf(dot(out, wh)) * mx) * schlick(Rs, dot(out, wh));
+      fr = diffuse + specular;
+      pdf = 0.5f * (fabsf(dot(out, n)) * ONE_OVER_PI + D * fabsf(dot(wh, n)) / (4.f * dot(in, wh)));
+      break;
+    }
+    case 3: {  // rough dielectric
+      V3 wo = -in;
+      V3 n = nor;
+      V3 wh = sample_ggx(m.alphaU, m.alphaV, u.x, u.y);
+      V3 uu = dpdu, ww = cross(uu, n);
+      wh = to_world(wh, uu, ww, n);
+      float ei = m.outsideIOR, et = m.insideIOR;
+      float cosi = dot(wo, n);
+      if (cosi > 0) { float t = et; et = ei; ei = t; }
+      float eta = ei / et;
+      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
+      float cosThetaI = dot(wo, wh);
+      float sin2ThetaI = fps::fmax_(0.f, 1.f - cosThetaI * cosThetaI);
+      float sin2ThetaT = eta * eta * sin2ThetaI;
+      float cosThetaT = sqrtf(1.f - sin2ThetaT < 0.f ? 0.f : 1.f - sin2ThetaT);
+      V3 rdir = reflect(-wo, wh);
+      V3 tdir = normalize((wo - wh * cosThetaI) * eta + (cosi < 0 ? -cosThetaT : cosThetaT) * wh);
+      if (sin2ThetaT > 1.f) {
+        out = rdir;
+        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
+        fr = m.specular * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
+        pdf = D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(wh, in)));
+        return;
+      }
+      float fresnel = dielectric_fresnel(fabsf(cosThetaI), fabsf(cosThetaT), ei, et);
+      if (u.z > fresnel) {
+        out = tdir;
+        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
+        float c = et * dot(out, wh) + ei * dot(in, wh);
+        fr = m.specular * ei * ei * D * G * (1.f - fresnel) * fabsf(dot(in, wh)) * fabsf(dot(out, wh)) /
+             (fabsf(dot(out, n)) * fabsf(dot(in, n)) * c * c);
+        fr = fr * (1.f / (eta * eta));
+        pdf = (1.f - fresnel) * D * fabsf(dot(wh, n)) * et * et * fabsf(dot(out, wh)) / (c * c);
+      } else {
+        out = rdir;
+        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
+        fr = m.specular * fresnel * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
+        pdf = D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(wh, in))) * fresnel;
+      }
+      break;
+    }
+    default:
+      out = v3(0, 0, 1); fr = v3(0, 0, 0); pdf = 0.f;
+  }
+}
+
+// Fr (pathtracer.cu:700-818)
+__device__ void eval_bsdf(const DevScene& S, const Mat& m, V3 in, V3 out, V3 nor, V2 uv, V3 dpdu, V3& fr, float& pdf) {
+  switch (m.type) {
+    case 0:
+      if (!same_hemisphere(in, out, nor)) { fr = v3(0, 0, 0); pdf = 0.f; return; }
+      fr = albedo(S, m, uv) * ONE_OVER_PI;
+      pdf = fabsf(dot(out, nor)) * ONE_OVER_PI;
+      break;
+    case 4: {
+      if (!same_hemisphere(in, out, nor)) { fr = v3(0, 0, 0); pdf = 0; return; }
+      V3 n = nor;
+      if (dot(nor, in) < 0) n = -n;
+      V3 wh = normalize(in + out);
+      float cosi = dot(out, wh);
+      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
+      float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
+      V3 F = conduct_fresnel(fabsf(cosi), m.eta, m.k);
+      fr = m.specular * F * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
+      pdf = D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(in, wh)));
+      break;
+    }
+    case 5: {
+      if (!same_hemisphere(in, out, nor)) { fr = v3(0, 0, 0); pdf = 0; return; }
+      V3 n = nor;
+      if (dot(nor, in) < 0) n = -n;
+      float cosThetaWo = fabsf(dot(in, n));
+      float cosThetaWi = fabsf(dot(out, n));
+      V3 Rd = albedo(S, m, uv);
+      V3 Rs = m.specular;
+      V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) * (1 - pow5(1 - .5f * cosThetaWi)) *
+                   (1 - pow5(1 - .5f * cosThetaWo));
+      V3 wh = normalize(in + out);
+      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
+      float mx = cosThetaWi > cosThetaWo ? cosThetaWi : cosThetaWo;
+      V3 specular = D / (4.f * fabsf(dot(out, wh)) * mx) * schlick(Rs, dot(out, wh));
+      fr = diffuse + specular;
+      pdf = 0.5f * (fabsf(dot(out, n)) * ONE_OVER_PI + D * fabsf(dot(wh, n)) / (4.f * dot(in, wh)));
+      break;
+    }
+    case 3: {
+      V3 wo = -in;
+      V3 n = nor;
+      bool refl = dot(in, n) * dot(out, n) > 0;
+      float ei = m.outsideIOR, et = m.insideIOR;
+      float cosi = dot(wo, n);
+      if (cosi > 0) { float t = et; et = ei; ei = t; }
+      V3 wh = normalize(-(ei * in + et * out));
+      float eta = ei / et;
+      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
+      float cosThetaI = dot(wo, wh);
+      float sin2ThetaI = fps::fmax_(0.f, 1.f - cosThetaI * cosThetaI);
+      float sin2ThetaT = eta * eta * sin2ThetaI;
+      float cosThetaT = sqrtf(1.f - sin2ThetaT < 0.f ? 0.f : 1.f - sin2ThetaT);
+      float fresnel = dielectric_fresnel(fabsf(cosThetaI), fabsf(cosThetaT), ei, et);
+      if (!refl) {
+        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
+        float c = et * dot(out, wh) + ei * dot(in, wh);
+        fr = m.specular * ei * ei * D * G * (1.f - fresnel) * fabsf(dot(in, wh)) * fabsf(dot(out, wh)) /
+             (fabsf(dot(out, n)) * fabsf(dot(in, n)) * c * c);
+        fr = fr * (1.f / (eta * eta));
+        pdf = (1.f - fresnel) * D * fabsf(dot(wh, n)) * et * et * fabsf(dot(out, wh)) / (c * c);
+      } else {
+        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
+        fr = m.specular * fresnel * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
+        pdf = fresnel * D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(wh, in)));
+      }
+      break;
+    }
+    default:  // mirror, dielectric
+      fr = v3(0, 0, 0);
+      pdf = 0.f;
+  }
+}
+
+// -------------------------------------------------------------------- lights
+struct LightRec { V3 v0, v1, v2, n0, n1, n2, radiance; float area; int prim; };
+__device__ inline void load_light(const DevScene& S, int idx, LightRec& l) {
+  const float4* r = S.lights + (size_t)idx * kLightF4;
+  float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5];
+  l.v0 = v3(a); l.v1 = v3(b); l.v2 = v3(c); l.n0 = v3(d); l.n1 = v3(e); l.n2 = v3(f);
+  l.area = a.w; l.radiance = v3(b.w, c.w, d.w); l.prim = __float_as_int(e.w);
+}
+
+// Environment lookup (infinite.h:46-93)
+__device__ inline V3 inf_texel(const DevInfinite& I, int x, int y) {
+  int width = I.w, height = I.h;
+  float rx = (float)(x - (x / width) * width);
+  float ry = (float)(y - (y / height) * height);
+  x = fps::f2i_((rx < 0) ? rx + width : rx);
+  y = fps::f2i_((ry < 0) ? ry + height : ry);
+  if (x < 0) x = 0;
+  if (x > width - 1) x = width - 1;
+  if (y < 0) y = 0;
+  if (y > height - 1) y = height - 1;
+  const float* p = I.data + ((size_t)y * width + x) * 3;
+  return v3(p[0], p[1], p[2]);
+}
+__device__ inline V3 inf_le(const DevInfinite& I, V3 dir) {
+  V3 u = v3(I.u), v = v3(I.v), w = v3(I.w_);
+  float costheta = dot(dir, v);
+  float theta = fps::acos_(costheta);
+  V3 d = normalize(dir - costheta * v);
+  float cosphi = dot(d, u);
+  float phi = fps::acos_(cosphi);
+  float c = dot(d, w);
+  phi = c > 0 ? TWOPI - phi : phi;
+  float uu = phi / TWOPI;
+  float vv = theta / PI;
+  float tu = 1.f - uu, tv = vv;
+  float xx = I.w * tu;
+  float yy = I.h * tv;
+  int x = fps::f2i_(floorf(xx));
+  int y = fps::f2i_(floorf(yy));
+  float dx = fabsf(xx - x);
+  float dy = fabsf(yy - y);
+  V3 c00 = inf_texel(I, x, y), c10 = inf_texel(I, x + 1, y);
+  V3 c01 = inf_texel(I, x, y + 1), c11 = inf_texel(I, x + 1, y + 1);
+  return (1 - dy) * ((1 - dx) * c00 + dx * c10) + dy * ((1 - dx) * c01 + dx * c11);
+}
+
+// LookUpLightDistribution (pathtracer.cu:181-190); no matching bin -> last bin.
+__device__ inline int pick_light(const DevScene& S, float u, float& pdf) {
+  int n = S.n_cdf;
+  for (int i = 0; i + 1 < n; ++i) {
+    float s = S.light_cdf[i], e = S.light_cdf[i + 1];
+    if (u >= s && u <= e) { pdf = e - s; return i; }
+  }
+  int last = n - 2;
+  if (last < 0) { pdf = 0.f; return 0; }
+  pdf = S.light_cdf[last + 1] - S.light_cdf[last];
+  return last;
+}
+
+// Light sampling step of Path/Volpath (pathtracer.cu:921-930): the light-pick
+// draw, two more draws, then Area::SampleLight (area.h:12-17 with
+// Triangle::SampleShape, Triangle.h:146-155) or Infinite::SampleLight
+// (infinite.h:16-35).  Outputs the shadow ray (dir, tmax).
+__device__ inline void sample_one_light(const DevScene& S, uint32_t& rng, V3 pos, V3& radiance, V3& sdir,
+                                        float& stmax, float& lightPdf, float& choicePdf) {
+  int idx = pick_light(S, rng_uniform(rng), choicePdf);
+  float ux = rng_uniform(rng);
+  float uy = rng_uniform(rng);
+  if (S.n_lights == 0 && !S.inf.valid) {
+    radiance = v3(0, 0, 0); lightPdf = 1.f; sdir = v3(0, 0, 1); stmax = 0.f;
+    return;
+  }
+  if (idx != S.n_lights) {
+    LightRec l;
+    load_light(S, idx, l);
+    float su1 = sqrtf(ux);
+    V2 uv = V2{1.f - su1, uy * su1};
+    V3 p = uv.x * l.v0 + uv.y * l.v1 + (1 - uv.x - uv.y) * l.v2;
+    V3 normal = normalize(uv.x * l.n0 + uv.y * l.n1 + (1 - uv.x - uv.y) * l.n2);
+    V3 dir = p - pos;
+    float pdf = 1.f / (l.area * fabsf(dot(normal, normalize(dir)))) * dot(dir, dir);
+    if (dot(normal, dir) >= 0.f) pdf = 0.f;
+    lightPdf = pdf;
+    radiance = pdf != 0.f ? l.radiance : v3(0.f, 0.f, 0.f);
+    sdir = normalize(dir);
+    stmax = sqrtf(dot(dir, dir) - S.epsilon);
+  } else {
+    float pdfW;
+    V3 dir = uniform_sphere(ux, uy, pdfW);
+    sdir = dir;
+    stmax = 2.f * S.inf.radius - S.epsilon;
+    lightPdf = pdfW;
+    radiance = inf_le(S.inf, dir);
+  }
+}
+
+// Queues a path writes to while being shaded.
+struct ShadeQueues {
+  RayQueue next;    // continuation rays (closest hit)
+  RayQueue shadow;  // light-sample rays (any hit)
+  RayQueue probe;   // BSDF-sampled direct-light rays (closest hit + weighting)
+};
+
+__device__ inline void push_ray(const RayQueue& q, bool want, int slot, V3 o, float tmin, V3 d, float tmax) {
+  uint32_t at = queue_reserve(q.count, want);
+  if (want) {
+    q.o[at] = f4(o, tmin);
+    q.d[at] = f4(d, tmax);
+    q.slot[at] = slot;
+  }
+}
+
+// Adds the two direct-light terms left pending by the previous vertex:
+// Li += beta * (Ld_light + Ld_bsdf)  (pathtracer.cu:984).
+__device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li) {
+  V3 x = v3(P.pend_x[slot]);
+  V3 y = v3(P.pend_y[slot]);
+  V3 bp = v3(P.beta_prev[slot]);
+  V3 Ld = x + y;
+  return Li + bp * Ld;
+}
+
+// One vertex of Path() (pathtracer.cu:897-1007) for every path whose
+// extension ray has been traced.
+__global__ __launch_bounds__(kWave) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out) {
+  const DevScene& S = L.S;
+  const PathState& P = L.P;
+  const uint32_t count = *cur.count;
+  const uint32_t rounds = (count + kWave - 1) / kWave;
+  for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+    uint32_t idx = r * kWave + threadIdx.x;
+    bool active = idx < count;
+    int slot = 0;
+    bool want_next = false, want_shadow = false, want_probe = false;
+    V3 no = v3(0, 0, 0), nd = v3(0, 0, 1), so = no, sd = nd, po = no, pd = nd;
+    float stmax = 0.f;
+    if (active) {
+      slot = cur.slot[idx];
+      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+      active = d4.w >= 0.f || __float_as_int(h4.y) >= 0;
+      if (!active) {
+        // slot outside the image: nothing to do, it never contributes
+      }
+    }
+    if (active) {
+      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+      V3 ro = v3(o4), rd = v3(d4);
+      Hit h;
+      h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+      float4 br = P.beta_rng[slot], lf = P.li_flags[slot];
+      V3 beta = v3(br), Li = v3(lf);
+      uint32_t rng = __float_as_uint(br.w), flags = __float_as_uint(lf.w);
+      int bounces = (int)(flags & kFBounceMask);
+      bool specular = (flags & kFSpecular) != 0;
+      if (flags & kFPending) {
+        Li = resolve_pending(P, slot, Li);
+        flags &= ~kFPending;
+      }
+      bool alive = true;
+      if (h.prim < 0) {
+        if ((bounces == 0 || specular) && S.inf.valid) Li = Li + beta * inf_le(S.inf, rd);
+        alive = false;
+      }
+      if (alive) {
+        Isect is;
+        load_isect(S, ro, rd, h, is);
+        V3 pos = is.pos, nor = is.n, dpdu = is.dpdu;
+        V2 uv = is.uv;
+        Mat m;
+        load_mat(S, is.mat, m);
+        if ((bounces == 0 || specular) && is.light != -1) {
+          // Area::Le (area.h:36-39)
+          LightRec l;
+          load_light(S, is.light, l);
+          V3 le = dot(nor, -rd) > 0.f ? l.radiance : v3(0, 0, 0);
+          Li = Li + beta * le;
+          alive = false;
+        }
+        if (alive) {
+          if (!is_delta(m.type)) {
+            // light sampling
+            V3 radiance, ldir;
+            float ltmax, lightPdf, choicePdf;
+            sample_one_light(S, rng, pos, radiance, ldir, ltmax, lightPdf, choicePdf);
+            V3 x = v3(0, 0, 0);
+            if (!is_black(radiance)) {
+              V3 fr;
+              float samplePdf;
+              eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
+              float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
+              x = weight * fr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
+              want_shadow = true;
+              so = pos; sd = ldir; stmax = ltmax;
+            }
+            // BSDF sampling for direct light
+            V3 us;
+            us.x = rng_uniform(rng); us.y = rng_uniform(rng); us.z = rng_uniform(rng);
+            V3 mo, mfr;
+            float mpdf;
+            sample_bsdf(S, m, -rd, nor, uv, dpdu, us, mo, mfr, mpdf);
+            float4 py = make_float4(0, 0, 0, 0);
+            float absdot = 0.f;
+            if (!is_black(mfr) && mpdf != 0) {
+              want_probe = true;
+              po = pos; pd = mo;
+              py = f4(mfr, mpdf);
+              absdot = fabsf(dot(mo, nor));
+            }
+            P.pend_x[slot] = f4(x, absdot);
+            P.pend_y[slot] = py;
+            P.beta_prev[slot] = f4(beta, 0.f);
+            flags |= kFPending;
+          }
+          // continuation
+          V3 u;
+          u.x = rng_uniform(rng); u.y = rng_uniform(rng); u.z = rng_uniform(rng);
+          V3 wo2, fr2;
+          float pdf2;
+          sample_bsdf(S, m, -rd, nor, uv, dpdu, u, wo2, fr2, pdf2);
+          if (is_black(fr2)) {
+            alive = false;
+          } else {
+            beta = beta * (fr2 * fabsf(dot(nor, wo2)) / pdf2);
+            specular = is_delta(m.type);
+            no = pos; nd = wo2;
+            if (bounces > 3) {
+              float illumate = fps::clamp_(1.f - luminance(beta), 0.f, 1.f);
+              if (rng_uniform(rng) < illumate) alive = false;
+              else beta = beta / (1 - illumate);
+            }
+            if (bounces + 1 >= S.maxDepth) alive = false;
+          }
+        }
+      }
+      want_next = alive;
+      flags = (flags & ~(kFBounceMask | kFSpecular)) | (uint32_t)(bounces + 1) | (specular ? kFSpecular : 0u);
+      P.beta_rng[slot] = f4(beta, rng);
+      P.li_flags[slot] = f4(Li, flags);
+    }
+    push_ray(out.next, want_next, slot, no, S.epsilon, nd, INFINITY);
+    push_ray(out.shadow, want_shadow, slot, so, S.epsilon, sd, stmax);
+    push_ray(out.probe, want_probe, slot, po, S.epsilon, pd, INFINITY);
+  }
+}
+
+// BSDF-sampled direct light (pathtracer.cu:949-983): closest hit along the
+// sampled direction; an emitter (or the environment on a miss) contributes
+// weight * fr * Le * |cos| / pdf into the path's pending term.
+__global__ __launch_bounds__(kWave) void k_probe(LaunchCtx L, RayQueue q) {
+  __shared__ int s_ref[kStackDepth][kWave];
+  __shared__ float s_tn[kStackDepth][kWave];
+  const DevScene& S = L.S;
+  const uint32_t count = *q.count;
+  for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
+    float4 o4 = q.o[idx], d4 = q.d[idx];
+    int slot = q.slot[idx];
+    V3 pos = v3(o4), out = v3(d4);
+    Hit h;
+    bool found = traverse<false>(S, pos, out, o4.w, d4.w, h, s_ref, s_tn, &L.stats->stack_overflow);
+    float4 py = L.P.pend_y[slot];
+    V3 fr = v3(py);
+    float pdf = py.w;
+    float absdot = L.P.pend_x[slot].w;
+    V3 y = v3(0, 0, 0);
+    if (found) {
+      int light = __float_as_int(S.shade[(size_t)h.prim * kShadeF4 + 6].y);
+      uint32_t type = __float_as_uint(S.isect[(size_t)h.prim * kIsectF4 + 2].w) & kPrimTypeMask;
+      if (type == 0u && light != -1) {
+        LightRec l;
+        load_light(S, light, l);
+        const float4* sh = S.shade + (size_t)h.prim * kShadeF4;
+        V3 n = normalize(v3(sh[0]) * (1.f - h.b1 - h.b2) + v3(sh[1]) * h.b1 + v3(sh[2]) * h.b2);
+        V3 p = pos + h.t * out;
+        V3 radiance = dot(n, -out) > 0.f ? l.radiance : v3(0, 0, 0);
+        if (!is_black(radiance)) {
+          float pdfA = 1.f / l.area;
+          float choicePdf = S.light_cdf[light + 1] - S.light_cdf[light];
+          float lenSquare = dot(p - pos, p - pos);
+          float costheta = fabsf(dot(n, out));
+          float lPdf = pdfA * lenSquare / (costheta);
+          float weight = power_heuristic(pdf, lPdf * choicePdf);
+          y = weight * fr * radiance * absdot / pdf;
+        }
+      }
+    } else if (S.inf.valid) {
+      V3 radiance = inf_le(S.inf, out);
+      float choicePdf = S.light_cdf[S.n_lights + 1] - S.light_cdf[S.n_lights];
+      float lightPdf = ONE_OVER_FOUR_PI;
+      float weight = power_heuristic(pdf, lightPdf * choicePdf);
+      y = weight * fr * radiance * absdot / pdf;
+    }
+    L.P.pend_y[slot] = f4(y, 0.f);
+  }
+}
+
+// Probe rays that were never issued leave (fr,pdf) = 0 in pend_y, which reads
+// as a zero contribution; issued ones are always overwritten by k_probe.
+
+// One vertex of Ao() (pathtracer.cu:841-868).
+__global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, ShadeQueues out) {
+  const DevScene& S = L.S;
+  const PathState& P = L.P;
+  const uint32_t count = *cur.count;
+  const uint32_t rounds = (count + kWave - 1) / kWave;
+  for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+    uint32_t idx = r * kWave + threadIdx.x;
+    bool want_shadow = false;
+    int slot = 0;
+    V3 so = v3(0, 0, 0), sd = v3(0, 0, 1);
+    if (idx < count) {
+      slot = cur.slot[idx];
+      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+      if (d4.w >= 0.f) {
+        V3 ro = v3(o4), rd = v3(d4);
+        Hit h;
+        h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+        float4 br = P.beta_rng[slot];
+        uint32_t rng = __float_as_uint(br.w);
+        uint32_t flags = 1u;
+        V3 Li = v3(0, 0, 0);
+        if (h.prim < 0) {
+          Li = v3(1, 1, 1);
+        } else {
+          Isect is;
+          load_isect(S, ro, rd, h, is);
+          V3 n = is.n;
+          float pdf = 0.f;
+          if (dot(-rd, n) < 0.f) n = -n;
+          float u1 = rng_uniform(rng);
+          float u2 = rng_uniform(rng);
+          V3 wi = cosine_hemisphere(u1, u2, pdf);
+          V3 s = is.dpdu;
+          V3 t = cross(n, s);
+          wi = to_world(wi, s, t, n);
+          float cosine = dot(wi, n);
+          float v = cosine / pdf;
+          P.pend_x[slot] = f4(v3(v, v, v), 0.f);
+          P.pend_y[slot] = make_float4(0, 0, 0, 0);
+          P.beta_prev[slot] = f4(v3(1, 1, 1), 0.f);
+          flags |= kFPending;
+          want_shadow = true;
+          so = is.pos; sd = wi;
+        }
+        P.beta_rng[slot] = f4(v3(br), rng);
+        P.li_flags[slot] = f4(Li, flags);
+      }
+    }
+    push_ray(out.shadow, want_shadow, slot, so, S.epsilon, sd, S.maxDist);
+  }
+}
+
+// ---- volumetric path tracing ------------------------------------------------
+__device__ inline V3 vexp(V3 c) { return v3(fps::exp_(c.x), fps::exp_(c.y), fps::exp_(c.z)); }
+struct MediumRec { V3 sigmaS, sigmaT; float g; };
+__device__ inline void load_medium(const DevScene& S, int idx, MediumRec& m) {
+  const float4* r = S.media + (size_t)idx * kMediumF4;
+  float4 a = r[0];
+  m.g = a.w; m.sigmaS = v3(r[1]); m.sigmaT = v3(r[2]);
+}
+__device__ inline V3 medium_tr(const DevScene& S, int medium, float tmax) {  // medium.h:13-16
+  MediumRec m;
+  load_medium(S, medium, m);
+  return vexp(m.sigmaT * (-tmax));
+}
+
+constexpr int kMaxCrossings = 1024;
+
+// Tr() (pathtracer.cu:307-331): transmittance along a shadow ray, marching
+// through index-matched boundaries; an opaque hit gives zero.
+__device__ V3 transmittance(const DevScene& S, V3 o, V3 d, float tmin, float tmax, int medium,
+                            int (*s_ref)[kWave], float (*s_tn)[kWave], Stats* stats, uint32_t& segs) {
+  V3 tr = v3(1, 1, 1);
+  float remaining = tmax;
+  float seg_tmax = tmax;
+  for (int guard = 0; guard < kMaxCrossings; ++guard) {
+    Hit h;
+    ++segs;
+    bool found = traverse<false>(S, o, d, tmin, seg_tmax, h, s_ref, s_tn, &stats->stack_overflow);
+    int mat = -1, med_in = -1, med_out = -1;
+    V3 n = v3(0, 0, 0);
+    if (found) {
+      Isect is;
+      load_isect(S, o, d, h, is);
+      mat = is.mat; med_in = is.med_in; med_out = is.med_out; n = is.n;
+      if (mat != -1) return v3(0, 0, 0);
+    }
+    float ray_tmax = found ? h.t : seg_tmax;
+    if (medium != -1) tr = tr * medium_tr(S, medium, ray_tmax);
+    if (!found) break;
+    int m = dot(d, n) > 0 ? med_out : med_in;
+    remaining -= ray_tmax;
+    o = o + ray_tmax * d;
+    medium = m;
+    tmin = S.epsilon;
+    seg_tmax = remaining;
+  }
+  return tr;
+}
+
+// One event of Volpath() (pathtracer.cu:1040-1223).  Shadow transmittance and
+// the BSDF-sampled light probe are walked inside this kernel; only the
+// continuation ray goes back through the extend stage.
+__global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, ShadeQueues out) {
+  __shared__ int s_ref[kStackDepth][kWave];
+  __shared__ float s_tn[kStackDepth][kWave];
+  const DevScene& S = L.S;
+  const PathState& P = L.P;
+  const uint32_t count = *cur.count;
+  const uint32_t rounds = (count + kWave - 1) / kWave;
+  uint32_t n_tr = 0, n_probe = 0;
+  for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+    uint32_t idx = r * kWave + threadIdx.x;
+    bool want_next = false;
+    int slot = 0;
+    V3 no = v3(0, 0, 0), nd = v3(0, 0, 1);
+    if (idx < count) {
+      slot = cur.slot[idx];
+      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+      if (d4.w >= 0.f || __float_as_int(h4.y) >= 0) {
+        V3 ro = v3(o4), rd = v3(d4);
+        Hit h;
+        h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+        float4 br = P.beta_rng[slot], lf = P.li_flags[slot];
+        V3 beta = v3(br), Li = v3(lf);
+        uint32_t rng = __float_as_uint(br.w), flags = __float_as_uint(lf.w);
+        int bounces = (int)(flags & kFBounceMask);
+        bool specular = (flags & kFSpecular) != 0;
+        int rmed = (int)((flags & kFMediumMask) >> kFMediumShift) - 1;
+        int crossings = (int)__float_as_uint(P.beta_prev[slot].w);
+        int nmed = rmed;
+        bool alive = true;
+        bool count_bounce = true;
+        if (h.prim < 0) {
+          if ((bounces == 0 || specular) && S.inf.valid) Li = Li + beta * inf_le(S.inf, rd);
+          alive = false;
+        } else {
+          Isect is;
+          load_isect(S, ro, rd, h, is);
+          V3 pos = is.pos, nor = is.n, dpdu = is.dpdu;
+          V2 uv = is.uv;
+          float rtmax = h.t;  // the reference's r.tmax after Intersect
+          float sampledDist = 0.f;
+          bool sampledMedium = false;
+          MediumRec med;
+          if (rmed != -1) {
+            // Homogeneous::Sample (medium.h:18-38)
+            load_medium(S, rmed, med);
+            int channel = fps::f2i_(rng_uniform(rng) * 3);
+            channel = channel == 3 ? 2 : channel;
+            float sT = channel == 0 ? med.sigmaT.x : (channel == 1 ? med.sigmaT.y : med.sigmaT.z);
+            float dist = -fps::log_(1 - rng_uniform(rng)) / sT;
+            dist = dist < rtmax ? dist : rtmax;
+            sampledMedium = dist < rtmax;
+            if (sampledMedium) sampledDist = dist;
+            V3 Tr = vexp(med.sigmaT * -dist);
+            V3 density = sampledMedium ? (med.sigmaT * Tr) : Tr;
+            float pdf = 0;
+            pdf += density.x; pdf += density.y; pdf += density.z;
+            pdf /= 3.f;
+            if (pdf == 0) pdf = 1;
+            beta = beta * (sampledMedium ? (Tr * med.sigmaS / pdf) : (Tr / pdf));
+          }
+          if (is_black(beta)) {
+            alive = false;
+          } else if (sampledMedium) {
+            V3 samplePos = ro + sampledDist * rd;
+            V3 radiance, ldir;
+            float ltmax, lightPdf, choicePdf;
+            sample_one_light(S, rng, samplePos, radiance, ldir, ltmax, lightPdf, choicePdf);
+            V3 tr = is_black(radiance) ? v3(1, 1, 1)
+                                       : transmittance(S, samplePos, ldir, S.epsilon, ltmax, rmed, s_ref, s_tn, L.stats, n_tr);
+            // Medium::Phase / SamplePhase (medium.h:146-186)
+            float phase;
+            if (med.g == 0) phase = ONE_OVER_FOUR_PI;
+            else {
+              float costheta = dot(-rd, ldir);
+              float cubicTerm = (1.f + med.g * med.g - 2.f * med.g * costheta);
+              phase = ONE_OVER_FOUR_PI * (1.f - med.g * med.g) / sqrtf(cubicTerm * cubicTerm * cubicTerm);
+            }
+            if (!is_black(radiance)) Li = Li + tr * beta * phase * radiance / (lightPdf * choicePdf);
+            float ux = rng_uniform(rng);
+            float uy = rng_uniform(rng);
+            V3 dir;
+            if (med.g == 0) {
+              float pdf;
+              dir = uniform_sphere(ux, uy, pdf);
+            } else {
+              float g = med.g, costheta;
+              if (fabsf(g) < 1e-3f) costheta = 1.f - 2.f * ux;
+              else {
+                float sqrtTerm = (1.f - g * g) / (1.f - g + 2.f * g * ux);
+                costheta = (1.f + g * g - sqrtTerm * sqrtTerm) / (2.f * g);
+              }
+              float sintheta = sqrtf(1.f - costheta * costheta);
+              float phi = TWOPI * uy;
+              float sinphi = fps::sin_(phi), cosphi = fps::cos_(phi);
+              dir = v3(sintheta * cosphi, sintheta * sinphi, costheta);
+            }
+            no = samplePos; nd = dir; nmed = rmed;
+            specular = false;
+          } else {
+            LightRec l;
+            bool emitter = (bounces == 0 || specular) && is.light != -1;
+            if (emitter) {
+              V3 tr = v3(1.f, 1.f, 1.f);
+              if (rmed != -1) tr = vexp(med.sigmaT * (-rtmax));
+              load_light(S, is.light, l);
+              V3 le = dot(nor, -rd) > 0.f ? l.radiance : v3(0, 0, 0);
+              Li = Li + tr * beta * le;
+              alive = false;
+            } else if (is.mat == -1) {
+              if (++crossings > kMaxCrossings) alive = false;
+              count_bounce = false;
+              nmed = dot(rd, is.n) > 0 ? is.med_out : is.med_in;
+              no = pos; nd = rd;
+            } else {
+              Mat m;
+              load_mat(S, is.mat, m);
+              if (!is_delta(m.type)) {
+                V3 Ld = v3(0.f, 0.f, 0.f);
+                V3 radiance, ldir;
+                float ltmax, lightPdf, choicePdf;
+                sample_one_light(S, rng, pos, radiance, ldir, ltmax, lightPdf, choicePdf);
+                if (!is_black(radiance)) {
+                  V3 fr;
+                  float samplePdf;
+                  eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
+                  V3 tr = transmittance(S, pos, ldir, S.epsilon, ltmax, rmed, s_ref, s_tn, L.stats, n_tr);
+                  float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
+                  Ld = Ld + weight * tr * fr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
+                }
+                V3 us;
+                us.x = rng_uniform(rng); us.y = rng_uniform(rng); us.z = rng_uniform(rng);
+                V3 mo, mfr;
+                float mpdf;
+                sample_bsdf(S, m, -rd, nor, uv, dpdu, us, mo, mfr, mpdf);
+                if (!is_black(mfr) && mpdf != 0) {
+                  Hit lh;
+                  ++n_probe;
+                  bool found = traverse<false>(S, pos, mo, S.epsilon, INFINITY, lh, s_ref, s_tn, &L.stats->stack_overflow);
+                  if (found) {
+                    int light = __float_as_int(S.shade[(size_t)lh.prim * kShadeF4 + 6].y);
+                    uint32_t type = __float_as_uint(S.isect[(size_t)lh.prim * kIsectF4 + 2].w) & kPrimTypeMask;
+                    if (type == 0u && light != -1) {
+                      load_light(S, light, l);
+                      const float4* sh = S.shade + (size_t)lh.prim * kShadeF4;
+                      V3 n = normalize(v3(sh[0]) * (1.f - lh.b1 - lh.b2) + v3(sh[1]) * lh.b1 + v3(sh[2]) * lh.b2);
+                      V3 p = pos + lh.t * mo;
+                      V3 rad2 = dot(n, -mo) > 0.f ? l.radiance : v3(0, 0, 0);
+                      if (!is_black(rad2)) {
+                        float pdfA = 1.f / l.area;
+                        float cp = S.light_cdf[light + 1] - S.light_cdf[light];
+                        float lenSquare = dot(p - pos, p - pos);
+                        float costheta = fabsf(dot(n, mo));
+                        float lPdf = pdfA * lenSquare / (costheta);
+                        float weight = power_heuristic(mpdf, lPdf * cp);
+                        V3 tr = v3(1.f, 1.f, 1.f);
+                        if (rmed != -1) tr = medium_tr(S, rmed, lh.t);
+                        Ld = Ld + weight * tr * mfr * rad2 * fabsf(dot(mo, nor)) / mpdf;
+                      }
+                    }
+                  } else if (S.inf.valid) {
+                    V3 rad2 = inf_le(S.inf, mo);
+                    float cp = S.light_cdf[S.n_lights + 1] - S.light_cdf[S.n_lights];
+                    float weight = power_heuristic(mpdf, ONE_OVER_FOUR_PI * cp);
+                    V3 tr = v3(1.f, 1.f, 1.f);
+                    if (rmed != -1) tr = medium_tr(S, rmed, INFINITY);
+                    Ld = Ld + weight * tr * mfr * rad2 * fabsf(dot(mo, nor)) / mpdf;
+                  }
+                }
+                Li = Li + beta * Ld;
+              }
+              V3 u;
+              u.x = rng_uniform(rng); u.y = rng_uniform(rng); u.z = rng_uniform(rng);
+              V3 wo2, fr2;
+              float pdf2;
+              sample_bsdf(S, m, -rd, nor, uv, dpdu, u, wo2, fr2, pdf2);
+              if (is_black(fr2)) {
+                alive = false;
+              } else {
+                beta = beta * (fr2 * fabsf(dot(nor, wo2)) / pdf2);
+                specular = is_delta(m.type);
+                int mm = dot(wo2, nor) > 0 ? is.med_out : is.med_in;
+                mm = dot(-rd, nor) * dot(wo2, nor) > 0 ? rmed : mm;
+                nmed = mm;
+                no = pos; nd = wo2;
+              }
+            }
+          }
+          if (alive && count_bounce) {
+            if (bounces > 3) {
+              float illumate = fps::clamp_(1.f - luminance(beta), 0.f, 1.f);
+              if (rng_uniform(rng) < illumate) alive = false;
+              else beta = beta / (1 - illumate);
+            }
+          }
+          if (count_bounce) {
+            if (bounces + 1 >= S.maxDepth) alive = false;
+            bounces += 1;
+          }
+        }
+        want_next = alive;
+        flags = (uint32_t)bounces | (specular ? kFSpecular : 0u) | ((uint32_t)(nmed + 1) << kFMediumShift);
+        P.beta_rng[slot] = f4(beta, rng);
+        P.li_flags[slot] = f4(Li, flags);
+        P.beta_prev[slot] = make_float4(0, 0, 0, __uint_as_float((uint32_t)crossings));
+      }
+    }
+    push_ray(out.next, want_next, slot, no, S.epsilon, nd, INFINITY);
+  }
+  // ray statistics: one atomic per wavefront
+  for (int off = 32; off > 0; off >>= 1) {
+    n_tr += (uint32_t)__shfl_down((int)n_tr, off, 64);
+    n_probe += (uint32_t)__shfl_down((int)n_probe, off, 64);
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    if (n_tr) atomicAdd(&L.stats->rays[3], (unsigned long long)n_tr);
+    if (n_probe) atomicAdd(&L.stats->rays[2], (unsigned long long)n_probe);
+  }
+}
+
+// ----------------------------------------------------------------- film
+// Ends every path of the batch and accumulates the film as Output() does
+// (pathtracer.cu:2502-2513): acc += colour of iteration first..first+n-1, in
+// iteration order.  A NaN/Inf sample adds nothing.  One thread per pixel, so
+// the sum order is fixed.
+__global__ void k_finish(LaunchCtx L, float* acc, uint32_t n_iter, int y0, int y1) {
+  const DevScene& S = L.S;
+  uint32_t npix = (uint32_t)S.width * (uint32_t)(y1 - y0);
+  uint32_t invalid = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+    uint32_t px = i % (uint32_t)S.width, py = (uint32_t)y0 + i / (uint32_t)S.width;
+    uint32_t local = pixel_slot(S, px, py);
+    uint32_t pixel = px + py * (uint32_t)S.width;
+    V3 a = v3(acc[3 * pixel], acc[3 * pixel + 1], acc[3 * pixel + 2]);
+    for (uint32_t k = 0; k < n_iter; ++k) {
+      uint32_t slot = k * (uint32_t)S.slots_per_iter + local;
+      float4 lf = L.P.li_flags[slot];
+      V3 Li = v3(lf);
+      uint32_t flags = __float_as_uint(lf.w);
+      if (flags & kFPending) Li = resolve_pending(L.P, (int)slot, Li);
+      bool bad = S.integrator == 0 ? has_nan(Li) : (has_nan(Li) || has_inf(Li));
+      if (bad) ++invalid;
+      else a = a + Li;
+    }
+    acc[3 * pixel] = a.x; acc[3 * pixel + 1] = a.y; acc[3 * pixel + 2] = a.z;
+  }
+  if (invalid) atomicAdd(&L.stats->invalid, (unsigned long long)invalid);
+}
+
+// out = tonemap(acc / iter) (pathtracer.cu:196-213, 2512-2516); mode 0 keeps
+// the linear mean.
+__global__ void k_resolve_film(const float* acc, float* out, uint32_t n_pix, float iter, int mode, int filmic) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += gridDim.x * blockDim.x) {
+    V3 c = v3(acc[3 * i], acc[3 * i + 1], acc[3 * i + 2]) / iter;
+    if (mode == 1) {
+      if (filmic) {
+        c = c - v3(0.004f, 0.004f, 0.004f);
+        c = v3(fps::fmax_(0.f, c.x), fps::fmax_(0.f, c.y), fps::fmax_(0.f, c.z));
+        c = (c * (6.2f * c + 0.5f)) / (c * (6.2f * c + 1.7f) + 0.06f);
+      } else {
+        float g = 1.f / 2.2f, e = 1.41421356f;
+        c = v3(fps::fmax_(c.x, 1e-5f), fps::fmax_(c.y, 1e-5f), fps::fmax_(c.z, 1e-5f));
+        c = v3(fps::pow_(c.x * e, g), fps::pow_(c.y * e, g), fps::pow_(c.z * e, g));
+      }
+    }
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+  }
+}
+
+// Primary-visibility map: primitive id per pixel from the traced camera queue.
+__global__ void k_gather_ids(LaunchCtx L, RayQueue q, int32_t* ids) {
+  const DevScene& S = L.S;
+  uint32_t npix = (uint32_t)S.width * (uint32_t)S.height;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+    uint32_t px = i % (uint32_t)S.width, py = i / (uint32_t)S.width;
+    ids[i] = __float_as_int(q.hit[pixel_slot(S, px, py)].y);
+  }
+}
+
+// Adds the three queue lengths of a finished bounce to the ray statistics and
+// clears the queues that the next shade pass appends to.
+__global__ void k_roll(Stats* st, const uint32_t* n_ext, const uint32_t* n_shadow, const uint32_t* n_probe,
+                       uint32_t* clear0, uint32_t* clear1, uint32_t* clear2, uint32_t ext_override) {
+  if (ext_override) st->rays[0] += ext_override;
+  else if (n_ext) st->rays[0] += *n_ext;
+  if (n_shadow) st->rays[1] += *n_shadow;
+  if (n_probe) st->rays[2] += *n_probe;
+  if (clear0) *clear0 = 0;
+  if (clear1) *clear1 = 0;
+  if (clear2) *clear2 = 0;
+}
+
+}  // namespace caster

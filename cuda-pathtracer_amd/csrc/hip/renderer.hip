@@ -1,0 +1,540 @@
+// Host side of the wavefront renderer and the C-ABI (include/caster.h).
+//
+// Replaces the reference's BeginRender / Render / EndRender
+// (CUDA-PathTracer/tracer/pathtracer.cu:2554-2742): instead of one megakernel
+// launch, one Output launch, a device synchronisation and a frame download per
+// sample, a call traces `iters_in_flight` samples per pixel as one batch of
+// paths through generate -> [extend -> shade -> shadow/probe]* -> finish on a
+// single HIP stream with no host round trip inside the batch (queue lengths
+// stay on the device), and the film stays resident until it is asked for.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/caster.h"
+#include "../scene/scene.h"
+#include "kernels.hip"
+
+namespace caster {
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define HIPCHECK(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(CASTER_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+static inline float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+static inline float as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline float as_float(uint32_t i) { float f; memcpy(&f, &i, 4); return f; }
+static inline float maxabs(f3 v) { return fps::fmax_(fps::fmax_(fabsf(v.x), fabsf(v.y)), fabsf(v.z)); }
+
+// Flat arrays in the device layout (device_scene.h), built once per scene.
+struct HostArrays {
+  std::vector<float4> nodes, isect, shade, lights, mats, media;
+  std::vector<uint32_t> tex_pool;
+  std::vector<int> tex_info;
+  std::vector<float> env;
+};
+
+static void build_arrays(const Scene& sc, HostArrays& A) {
+  const size_t np = sc.prims.size();
+  A.isect.assign(np * kIsectF4, make_float4(0, 0, 0, 0));
+  A.shade.assign(np * kShadeF4, make_float4(0, 0, 0, 0));
+  std::vector<uint32_t> tail(np, 0);
+  for (size_t i = 0; i < np; ++i) tail[i] = (uint32_t)sc.prims[i].type & kPrimTypeMask;
+  // Inner nodes only: each carries both children's boxes (bvh.h:19-29 keeps a
+  // node's own box instead).  Leaf ranges end at the primitive flagged "last".
+  std::vector<int> dev_index(sc.nodes.size(), -1);
+  int n_inner = 0;
+  for (size_t i = 0; i < sc.nodes.size(); ++i) if (!sc.nodes[i].leaf) dev_index[i] = n_inner++;
+  auto child_ref = [&](int host) {
+    const Node& n = sc.nodes[host];
+    if (!n.leaf) return dev_index[host];
+    if (n.start < 0) return kRefEmpty;
+    tail[n.end] |= kPrimLastInLeaf;
+    return ~n.start;
+  };
+  const f3 einf_lo = mk3(INFINITY, INFINITY, INFINITY), einf_hi = mk3(-INFINITY, -INFINITY, -INFINITY);
+  if (!sc.nodes.empty() && sc.nodes[0].leaf) {
+    A.nodes.resize(kNodeF4);
+    A.nodes[0] = mk4(sc.nodes[0].lo, as_float(child_ref(0)));
+    A.nodes[1] = mk4(sc.nodes[0].hi, as_float(kRefEmpty));
+    A.nodes[2] = mk4(einf_lo, 0.f);
+    A.nodes[3] = mk4(einf_hi, 0.f);
+  } else {
+    A.nodes.resize((size_t)n_inner * kNodeF4);
+    for (size_t i = 0; i < sc.nodes.size(); ++i) {
+      if (sc.nodes[i].leaf) continue;
+      int c0 = (int)i + 1, c1 = sc.nodes[i].second;
+      float4* d = &A.nodes[(size_t)dev_index[i] * kNodeF4];
+      d[0] = mk4(sc.nodes[c0].lo, as_float(child_ref(c0)));
+      d[1] = mk4(sc.nodes[c0].hi, as_float(child_ref(c1)));
+      d[2] = mk4(sc.nodes[c1].lo, 0.f);
+      d[3] = mk4(sc.nodes[c1].hi, 0.f);
+    }
+  }
+  for (size_t i = 0; i < np; ++i) {
+    const Prim& p = sc.prims[i];
+    float4* ir = &A.isect[i * kIsectF4];
+    float4* sh = &A.shade[i * kShadeF4];
+    if (p.type == GT_TRIANGLE) {
+      f3 p1 = p.v[0].v, p2 = p.v[1].v, p3 = p.v[2].v;
+      float maxE = fps::fmax_(fps::fmax_(maxabs(p1), maxabs(p2)), maxabs(p3));
+      ir[0] = mk4(p1, maxE);
+      ir[1] = mk4(p2 - p1, maxabs(p1));
+      ir[2] = mk4(p3 - p1, as_float(tail[i]));
+      sh[0] = mk4(p.v[0].n, p.v[0].uv.x);
+      sh[1] = mk4(p.v[1].n, p.v[0].uv.y);
+      sh[2] = mk4(p.v[2].n, p.v[1].uv.x);
+      sh[3] = mk4(p.v[0].t, p.v[1].uv.y);
+      sh[4] = mk4(p.v[1].t, p.v[2].uv.x);
+      sh[5] = mk4(p.v[2].t, p.v[2].uv.y);
+    } else if (p.type == GT_SPHERE) {
+      ir[0] = mk4(p.p0, p.w0);
+      ir[2] = make_float4(0, 0, 0, as_float(tail[i]));
+      sh[0] = mk4(p.p0, p.w0);
+    } else {
+      ir[0] = mk4(p.p0, p.w0);
+      ir[1] = mk4(p.p1, p.w1);
+      ir[2] = make_float4(0, 0, 0, as_float(tail[i]));
+      sh[0] = mk4(p.p0, p.w0);
+      sh[1] = mk4(p.p1, p.w1);
+    }
+    sh[6] = make_float4(as_float(p.mat), as_float(p.light), as_float(p.med_in), as_float(p.med_out));
+  }
+  A.lights.resize(sc.lights.size() * kLightF4);
+  for (size_t i = 0; i < sc.lights.size(); ++i) {
+    const Light& l = sc.lights[i];
+    const Prim& p = sc.prims[l.prim];
+    f3 e1 = p.v[1].v - p.v[0].v, e2 = p.v[2].v - p.v[0].v;
+    f3 c = cross3(e1, e2);
+    float area = sqrtf(dot3(c, c)) * 0.5f;  // Triangle.h:81-85
+    float4* d = &A.lights[i * kLightF4];
+    d[0] = mk4(p.v[0].v, area);
+    d[1] = mk4(p.v[1].v, l.radiance.x);
+    d[2] = mk4(p.v[2].v, l.radiance.y);
+    d[3] = mk4(p.v[0].n, l.radiance.z);
+    d[4] = mk4(p.v[1].n, as_float(l.prim));
+    d[5] = mk4(p.v[2].n, as_float(l.medium));
+  }
+  A.mats.resize(std::max<size_t>(1, sc.materials.size()) * kMatF4, make_float4(0, 0, 0, 0));
+  for (size_t i = 0; i < sc.materials.size(); ++i) {
+    const Material& m = sc.materials[i];
+    float4* d = &A.mats[i * kMatF4];
+    d[0] = make_float4(as_float(m.type), m.alphaU, m.alphaV, m.insideIOR);
+    d[1] = make_float4(m.outsideIOR, as_float(m.tex), 0.f, 0.f);
+    d[2] = mk4(m.k, 0.f);
+    d[3] = mk4(m.eta, 0.f);
+    d[4] = mk4(m.diffuse, 0.f);
+    d[5] = mk4(m.specular, 0.f);
+  }
+  A.media.resize(std::max<size_t>(1, sc.media.size()) * kMediumF4, make_float4(0, 0, 0, 0));
+  for (size_t i = 0; i < sc.media.size(); ++i) {
+    const Medium& m = sc.media[i];
+    float4* d = &A.media[i * kMediumF4];
+    d[0] = mk4(m.sigmaA, m.g);
+    d[1] = mk4(m.sigmaS, as_float(m.type));
+    d[2] = mk4(m.sigmaT, 0.f);
+  }
+  for (const Texture& t : sc.textures) {
+    A.tex_info.push_back((int)A.tex_pool.size());
+    A.tex_info.push_back(t.w);
+    A.tex_info.push_back(t.h);
+    size_t n = (size_t)t.w * t.h;
+    for (size_t k = 0; k < n; ++k) {
+      const uint8_t* c = &t.rgba[k * 4];
+      A.tex_pool.push_back((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24));
+    }
+  }
+  if (sc.infinite.valid) {
+    A.env.resize(sc.infinite.data.size() * 3);
+    for (size_t k = 0; k < sc.infinite.data.size(); ++k) {
+      A.env[3 * k] = sc.infinite.data[k].x; A.env[3 * k + 1] = sc.infinite.data[k].y; A.env[3 * k + 2] = sc.infinite.data[k].z;
+    }
+  }
+}
+
+static float gamma_n(int n) {  // common.h:111-114: double arithmetic, float result
+  const double me = (double)1.192092896e-07F * 0.5;
+  return (float)((n * me) / (1 - n * me));
+}
+
+}  // namespace caster
+
+using namespace caster;
+
+struct caster_scene {
+  Scene scene;
+};
+
+struct caster_renderer {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  DevScene S{};
+  PathState P{};
+  RayQueue ext[2]{}, shadow{}, probe{};
+  uint32_t* counters = nullptr;  // ext0, ext1, shadow, probe
+  Stats* stats = nullptr;
+  float* acc = nullptr;
+  float* film_tmp = nullptr;
+  int32_t* ids = nullptr;
+  int iters_in_flight = 1;
+  uint32_t pool_slots = 0;
+  uint32_t iterations = 0;
+  uint64_t samples = 0;
+  int y0 = 0, y1 = 0;
+  int n_cu = 256;
+};
+
+namespace caster {
+
+template <class T>
+static int dev_alloc(caster_renderer* r, T** out, size_t count) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIPCHECK(hipMalloc(&p, bytes));
+  r->allocs.push_back(p);
+  *out = (T*)p;
+  return CASTER_OK;
+}
+template <class T>
+static int dev_upload(caster_renderer* r, const T** out, const std::vector<T>& v) {
+  T* p = nullptr;
+  int rc = dev_alloc(r, &p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = p;
+  return CASTER_OK;
+}
+
+static int alloc_queue(caster_renderer* r, RayQueue& q, uint32_t n, bool with_hit, uint32_t* counter) {
+  int rc;
+  if ((rc = dev_alloc(r, &q.o, n))) return rc;
+  if ((rc = dev_alloc(r, &q.d, n))) return rc;
+  if ((rc = dev_alloc(r, &q.slot, n))) return rc;
+  q.hit = nullptr;
+  if (with_hit && (rc = dev_alloc(r, &q.hit, n))) return rc;
+  q.count = counter;
+  return CASTER_OK;
+}
+
+static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caster_renderer* r) {
+  r->device = device_id;
+  HIPCHECK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, device_id));
+  r->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+
+  HostArrays A;
+  build_arrays(sc, A);
+  DevScene& S = r->S;
+  int rc;
+  if ((rc = dev_upload(r, &S.nodes, A.nodes))) return rc;
+  if ((rc = dev_upload(r, &S.isect, A.isect))) return rc;
+  if ((rc = dev_upload(r, &S.shade, A.shade))) return rc;
+  if ((rc = dev_upload(r, &S.lights, A.lights))) return rc;
+  if ((rc = dev_upload(r, &S.mats, A.mats))) return rc;
+  if ((rc = dev_upload(r, &S.media, A.media))) return rc;
+  if ((rc = dev_upload(r, &S.light_cdf, sc.light_cdf))) return rc;
+  if ((rc = dev_upload(r, &S.tex_pool, A.tex_pool))) return rc;
+  if ((rc = dev_upload(r, &S.tex_info, A.tex_info))) return rc;
+  if ((rc = dev_upload(r, &S.inf.data, A.env))) return rc;
+  S.n_prims = (int)sc.prims.size();
+  S.n_nodes = (int)(A.nodes.size() / kNodeF4);
+  S.n_lights = (int)sc.lights.size();
+  S.n_cdf = (int)sc.light_cdf.size();
+  const Camera& c = sc.camera;
+  DevCamera& dc = S.cam;
+  const f3* src[4] = {&c.position, &c.u, &c.v, &c.w};
+  float* dst[4] = {dc.pos, dc.u, dc.v, dc.w};
+  for (int k = 0; k < 4; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
+  dc.res_x = c.res_x; dc.res_y = c.res_y; dc.distance = c.distance;
+  dc.apertureRadius = c.apertureRadius; dc.focalDistance = c.focalDistance;
+  dc.half_w = c.half_w; dc.half_h = c.half_h; dc.p2s_x = c.p2s_x; dc.p2s_y = c.p2s_y; dc.ratio = c.ratio;
+  dc.environment = c.environment; dc.medium = c.medium; dc.filmic = c.filmic;
+  S.inf.valid = sc.infinite.valid; S.inf.w = sc.infinite.w; S.inf.h = sc.infinite.h;
+  S.inf.radius = sc.infinite.radius;
+  const f3* isrc[3] = {&sc.infinite.u, &sc.infinite.v, &sc.infinite.w_};
+  float* idst[3] = {S.inf.u, S.inf.v, S.inf.w_};
+  for (int k = 0; k < 3; ++k) { idst[k][0] = isrc[k]->x; idst[k][1] = isrc[k]->y; idst[k][2] = isrc[k]->z; }
+  S.epsilon = sc.epsilon;
+  S.g1 = gamma_n(1); S.g2 = gamma_n(2); S.g3 = gamma_n(3);
+  S.box_scale = 1 + 2 * S.g3;
+  S.integrator = sc.integrator; S.maxDepth = sc.maxDepth; S.maxDist = sc.maxDist;
+  S.width = sc.width; S.height = sc.height;
+  S.tiles_x = (sc.width + 7) / 8; S.tiles_y = (sc.height + 7) / 8;
+  S.slots_per_iter = S.tiles_x * S.tiles_y * 64;
+  r->y0 = 0; r->y1 = sc.height;
+
+  if (iters_in_flight <= 0) {
+    long long target = 16ll << 20;
+    iters_in_flight = (int)std::max<long long>(1, std::min<long long>(64, target / S.slots_per_iter));
+  }
+  r->iters_in_flight = iters_in_flight;
+  r->pool_slots = (uint32_t)S.slots_per_iter * (uint32_t)iters_in_flight;
+  const uint32_t n = r->pool_slots;
+  if ((rc = dev_alloc(r, &r->P.beta_rng, n))) return rc;
+  if ((rc = dev_alloc(r, &r->P.li_flags, n))) return rc;
+  if ((rc = dev_alloc(r, &r->P.pend_x, n))) return rc;
+  if ((rc = dev_alloc(r, &r->P.pend_y, n))) return rc;
+  if ((rc = dev_alloc(r, &r->P.beta_prev, n))) return rc;
+  if ((rc = dev_alloc(r, &r->counters, 8))) return rc;
+  HIPCHECK(hipMemset(r->counters, 0, 8 * sizeof(uint32_t)));
+  if ((rc = alloc_queue(r, r->ext[0], n, true, r->counters + 0))) return rc;
+  if ((rc = alloc_queue(r, r->ext[1], n, true, r->counters + 1))) return rc;
+  if ((rc = alloc_queue(r, r->shadow, n, false, r->counters + 2))) return rc;
+  if ((rc = alloc_queue(r, r->probe, n, false, r->counters + 3))) return rc;
+  if ((rc = dev_alloc(r, &r->stats, 1))) return rc;
+  HIPCHECK(hipMemset(r->stats, 0, sizeof(Stats)));
+  size_t npix = (size_t)sc.width * sc.height;
+  if ((rc = dev_alloc(r, &r->acc, npix * 3))) return rc;
+  HIPCHECK(hipMemset(r->acc, 0, npix * 3 * sizeof(float)));
+  if ((rc = dev_alloc(r, &r->film_tmp, npix * 3))) return rc;
+  if ((rc = dev_alloc(r, &r->ids, npix))) return rc;
+  return CASTER_OK;
+}
+
+static inline LaunchCtx ctx_of(caster_renderer* r) { return LaunchCtx{r->S, r->P, r->stats}; }
+
+// Enqueues one batch of `n` iterations starting at `first`.
+static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
+  const DevScene& S = r->S;
+  hipStream_t st = r->stream;
+  LaunchCtx L = ctx_of(r);
+  const uint32_t total = (uint32_t)S.slots_per_iter * n;
+  const int walk_grid = r->n_cu * 10;   // 16 KB of LDS stack per wavefront: 10 wavefronts per CU
+  const int shade_grid = r->n_cu * 16;
+  const int gen_grid = (int)std::min<uint32_t>((total + kWave - 1) / kWave, (uint32_t)r->n_cu * 32);
+  int cur = 0;
+  hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, r->ext[0], first, n, r->y0, r->y1);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, r->ext[0].count, total);
+  hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                     (const uint32_t*)nullptr, r->ext[1].count, r->shadow.count, r->probe.count, 0u);
+  const uint32_t live_rays = (uint32_t)S.width * (uint32_t)(r->y1 - r->y0) * n;
+  auto bounce = [&](int b) {
+    RayQueue& q = r->ext[cur];
+    ShadeQueues out{r->ext[cur ^ 1], r->shadow, r->probe};
+    hipLaunchKernelGGL(k_extend, dim3(walk_grid), dim3(kWave), 0, st, L, q);
+    if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
+    else if (S.integrator == IT_VPT) hipLaunchKernelGGL(k_shade_vpt, dim3(walk_grid), dim3(kWave), 0, st, L, q, out);
+    else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
+    if (S.integrator != IT_VPT) {
+      hipLaunchKernelGGL(k_shadow, dim3(walk_grid), dim3(kWave), 0, st, L, r->shadow);
+      if (S.integrator == IT_PT) hipLaunchKernelGGL(k_probe, dim3(walk_grid), dim3(kWave), 0, st, L, r->probe);
+    }
+    // the camera queue also holds slots outside the image / row range: count only live rays
+    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)q.count,
+                       (const uint32_t*)r->shadow.count, (const uint32_t*)r->probe.count, q.count, r->shadow.count,
+                       r->probe.count, b == 0 ? live_rays : 0u);
+    cur ^= 1;
+  };
+  if (S.integrator == IT_AO) {
+    bounce(0);
+  } else if (S.integrator == IT_PT) {
+    for (int b = 0; b < S.maxDepth; ++b) bounce(b);
+  } else {
+    // Boundary crossings do not consume a bounce (pathtracer.cu:1106-1113), so
+    // the number of rounds is data dependent: after maxDepth rounds keep going
+    // while the queue is non-empty.
+    int b = 0;
+    for (; b < S.maxDepth; ++b) bounce(b);
+    for (;; ++b) {
+      uint32_t left = 0;
+      HIPCHECK(hipMemcpyAsync(&left, r->ext[cur].count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIPCHECK(hipStreamSynchronize(st));
+      if (left == 0 || b > S.maxDepth + kMaxCrossings) break;
+      bounce(b);
+    }
+  }
+  hipLaunchKernelGGL(k_finish, dim3(r->n_cu * 8), dim3(256), 0, st, L, r->acc, n, r->y0, r->y1);
+  HIPCHECK(hipGetLastError());
+  return CASTER_OK;
+}
+
+}  // namespace caster
+
+extern "C" {
+
+const char* caster_last_error(void) { return g_last_error.c_str(); }
+
+int caster_scene_load(const char* json_path, caster_scene** out) {
+  if (!json_path || !out) return fail(CASTER_ERR_ARG, "caster_scene_load: null argument");
+  caster_scene* s = new caster_scene();
+  std::string err;
+  if (!load_scene(json_path, s->scene, err)) {
+    delete s;
+    return fail(CASTER_ERR_SCENE, err);
+  }
+  *out = s;
+  return CASTER_OK;
+}
+
+void caster_scene_free(caster_scene* s) { delete s; }
+
+int caster_scene_get_info(const caster_scene* s, caster_scene_info* o) {
+  if (!s || !o) return fail(CASTER_ERR_ARG, "caster_scene_get_info: null argument");
+  const Scene& sc = s->scene;
+  o->width = sc.width; o->height = sc.height; o->integrator = sc.integrator; o->max_depth = sc.maxDepth;
+  o->n_prims = (int)sc.prims.size(); o->n_nodes = (int)sc.nodes.size(); o->n_lights = (int)sc.lights.size();
+  o->n_materials = (int)sc.materials.size(); o->n_media = (int)sc.media.size();
+  o->n_textures = (int)sc.textures.size(); o->has_environment = sc.infinite.valid; o->filmic = sc.camera.filmic;
+  o->max_dist = sc.maxDist; o->epsilon = sc.epsilon;
+  return CASTER_OK;
+}
+
+void caster_end(caster_renderer* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+  for (void* p : r->allocs) (void)hipFree(p);
+  delete r;
+}
+
+int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, caster_renderer** out) {
+  if (!s || !out) return fail(CASTER_ERR_ARG, "caster_begin: null argument");
+  if (s->scene.prims.empty()) return fail(CASTER_ERR_SCENE, "caster_begin: scene has no primitives");
+  for (const Prim& p : s->scene.prims)
+    if (p.mat < 0 && s->scene.integrator == IT_PT)
+      return fail(CASTER_ERR_SCENE, "caster_begin: a shape without a material needs the vpt integrator");
+  caster_renderer* r = new caster_renderer();
+  int rc = begin_impl(s->scene, device_id, iters_in_flight, r);
+  if (rc) { caster_end(r); return rc; }
+  *out = r;
+  return CASTER_OK;
+}
+
+int caster_set_rows(caster_renderer* r, int y0, int y1) {
+  if (!r || y0 < 0 || y1 > r->S.height || y0 > y1) return fail(CASTER_ERR_ARG, "caster_set_rows: bad range");
+  r->y0 = y0; r->y1 = y1;
+  return CASTER_OK;
+}
+
+int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset) {
+  if (!r) return fail(CASTER_ERR_ARG, "caster_render: null renderer");
+  HIPCHECK(hipSetDevice(r->device));
+  if (reset) {
+    HIPCHECK(hipMemsetAsync(r->acc, 0, (size_t)r->S.width * r->S.height * 3 * sizeof(float), r->stream));
+    r->iterations = 0;
+  }
+  uint32_t done = 0;
+  while (done < n_iter) {
+    uint32_t n = std::min<uint32_t>(n_iter - done, (uint32_t)r->iters_in_flight);
+    int rc = enqueue_batch(r, first_iter + done, n);
+    if (rc) return rc;
+    done += n;
+  }
+  r->iterations += n_iter;
+  r->samples += (uint64_t)r->S.width * (uint64_t)(r->y1 - r->y0) * n_iter;
+  return CASTER_OK;
+}
+
+int caster_sync(caster_renderer* r) {
+  if (!r) return fail(CASTER_ERR_ARG, "caster_sync: null renderer");
+  HIPCHECK(hipSetDevice(r->device));
+  HIPCHECK(hipStreamSynchronize(r->stream));
+  return CASTER_OK;
+}
+
+int caster_render(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset) {
+  int rc = caster_render_async(r, first_iter, n_iter, reset);
+  if (rc) return rc;
+  rc = caster_sync(r);
+  if (rc) return rc;
+  caster_stats st;
+  rc = caster_get_stats(r, &st);
+  if (rc) return rc;
+  if (st.stack_overflow) return fail(CASTER_ERR_OVERFLOW, "BVH traversal stack overflow: image is invalid");
+  return CASTER_OK;
+}
+
+int caster_read_film_device(caster_renderer* r, float* dev, int mode) {
+  if (!r || !dev || mode < 0 || mode > 2) return fail(CASTER_ERR_ARG, "caster_read_film: bad argument");
+  HIPCHECK(hipSetDevice(r->device));
+  uint32_t npix = (uint32_t)r->S.width * (uint32_t)r->S.height;
+  float div = mode == 2 ? 1.f : (float)(r->iterations ? r->iterations : 1u);
+  hipLaunchKernelGGL(k_resolve_film, dim3(r->n_cu * 4), dim3(256), 0, r->stream, (const float*)r->acc, dev, npix, div,
+                     mode == 1 ? 1 : 0, r->S.cam.filmic);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(r->stream));
+  return CASTER_OK;
+}
+
+int caster_read_film(caster_renderer* r, float* rgb, int mode) {
+  if (!r || !rgb) return fail(CASTER_ERR_ARG, "caster_read_film: null argument");
+  int rc = caster_read_film_device(r, r->film_tmp, mode);
+  if (rc) return rc;
+  HIPCHECK(hipMemcpy(rgb, r->film_tmp, (size_t)r->S.width * r->S.height * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  return CASTER_OK;
+}
+
+__global__ void k_film_add(float* acc, const float* add, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc[i] += add[i];
+}
+
+int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t n_iters) {
+  if (!r || !sum_device) return fail(CASTER_ERR_ARG, "caster_film_add_device: null argument");
+  HIPCHECK(hipSetDevice(r->device));
+  uint32_t n = (uint32_t)r->S.width * (uint32_t)r->S.height * 3u;
+  hipLaunchKernelGGL(k_film_add, dim3(r->n_cu * 4), dim3(256), 0, r->stream, r->acc, sum_device, n);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(r->stream));
+  r->iterations += n_iters;
+  return CASTER_OK;
+}
+
+int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
+  if (!r || !ids) return fail(CASTER_ERR_ARG, "caster_primary_ids: null argument");
+  HIPCHECK(hipSetDevice(r->device));
+  LaunchCtx L = ctx_of(r);
+  const uint32_t total = (uint32_t)r->S.slots_per_iter;
+  hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, r->stream, L, r->ext[0], iter, 1u,
+                     0, r->S.height);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->ext[0].count, total);
+  hipLaunchKernelGGL(k_extend, dim3(r->n_cu * 10), dim3(kWave), 0, r->stream, L, r->ext[0]);
+  hipLaunchKernelGGL(k_gather_ids, dim3(r->n_cu * 4), dim3(256), 0, r->stream, L, r->ext[0], r->ids);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->ext[0].count, 0u);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(r->stream));
+  HIPCHECK(hipMemcpy(ids, r->ids, (size_t)r->S.width * r->S.height * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return CASTER_OK;
+}
+
+int caster_get_stats(caster_renderer* r, caster_stats* out) {
+  if (!r || !out) return fail(CASTER_ERR_ARG, "caster_get_stats: null argument");
+  HIPCHECK(hipSetDevice(r->device));
+  HIPCHECK(hipStreamSynchronize(r->stream));
+  Stats st;
+  HIPCHECK(hipMemcpy(&st, r->stats, sizeof(Stats), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; ++i) out->rays[i] = st.rays[i];
+  out->samples = r->samples;
+  out->invalid = st.invalid;
+  out->stack_overflow = st.stack_overflow;
+  return CASTER_OK;
+}
+
+int caster_reset_stats(caster_renderer* r) {
+  if (!r) return fail(CASTER_ERR_ARG, "caster_reset_stats: null renderer");
+  HIPCHECK(hipSetDevice(r->device));
+  HIPCHECK(hipStreamSynchronize(r->stream));
+  HIPCHECK(hipMemset(r->stats, 0, sizeof(Stats)));
+  r->samples = 0;
+  return CASTER_OK;
+}
+
+uint32_t caster_iterations(const caster_renderer* r) { return r ? r->iterations : 0; }
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+/* C-ABI of the MI355X render hot path (libcaster.so).
+ *
+ * Drop-in boundary for the reference's device runtime,
+ *   void BeginRender(Scene&, unsigned w, unsigned h, float eps);
+ *   void Render(Scene&, unsigned w, unsigned h, Camera*, unsigned iter,
+ *               bool reset, float3* output);
+ *   void EndRender();
+ * (CUDA-PathTracer/tracer/pathtracer.h:8-10), and for the scene loading that
+ * feeds it (InitScene, CUDA-PathTracer/tracer/parsescene.h:26-27).  Plain
+ * pointers and sizes only; every call returns a status code and never throws.
+ * One host thread per renderer handle.
+ *
+ * Image convention (as the reference's kernels write it,
+ * CUDA-PathTracer/tracer/Camera.h:57-58): W*H*3 floats, RGB interleaved,
+ * pixel = x + y*W with row 0 the BOTTOM scanline. */
+#ifndef CASTER_H
+#define CASTER_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct caster_scene caster_scene;
+typedef struct caster_renderer caster_renderer;
+
+enum {
+  CASTER_OK = 0,
+  CASTER_ERR_ARG = 1,      /* null / out-of-range argument */
+  CASTER_ERR_SCENE = 2,    /* scene file could not be read or is malformed */
+  CASTER_ERR_DEVICE = 3,   /* a HIP call failed */
+  CASTER_ERR_OVERFLOW = 4  /* BVH deeper than the traversal stack: image invalid */
+};
+
+typedef struct caster_scene_info {
+  int32_t width, height;
+  int32_t integrator;      /* 0 ao, 1 pt, 2 vpt (IntegratorType, scene.h:13-22) */
+  int32_t max_depth;
+  int32_t n_prims, n_nodes, n_lights, n_materials, n_media, n_textures;
+  int32_t has_environment;
+  int32_t filmic;
+  float max_dist, epsilon;
+} caster_scene_info;
+
+typedef struct caster_stats {
+  /* rays traced since caster_begin / the last reset: 0 extension (camera +
+     continuation), 1 shadow (any-hit), 2 BSDF-sampled light probe, 3
+     transmittance segment */
+  uint64_t rays[4];
+  uint64_t samples;        /* camera samples = pixels * iterations rendered */
+  uint64_t invalid;        /* samples dropped because their radiance was NaN/Inf */
+  uint64_t stack_overflow; /* must stay 0 */
+} caster_stats;
+
+/* Replaces InitScene (parsescene.cpp:600-617): parses the JSON scene file,
+   loads its meshes/textures, builds the BVH and the light distribution. */
+int caster_scene_load(const char* json_path, caster_scene** out);
+void caster_scene_free(caster_scene* s);
+int caster_scene_get_info(const caster_scene* s, caster_scene_info* out);
+
+/* Replaces BeginRender (pathtracer.cu:2554-2681): uploads the scene to HIP
+   device `device_id` and allocates the film and path pools.  The renderer
+   keeps no reference to `s` afterwards.  `iters_in_flight` is how many
+   iterations (samples per pixel) are traced together as one batch of paths;
+   0 picks a default. */
+int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, caster_renderer** out);
+
+/* Restricts this renderer to scanlines [y0, y1) of the image (tile sharding
+   across GPUs).  Default is the whole image. */
+int caster_set_rows(caster_renderer* r, int y0, int y1);
+
+/* Replaces n_iter calls of Render (pathtracer.cu:2691-2742) for iterations
+   first_iter .. first_iter+n_iter-1 (the reference counts from 1,
+   CudaRender.cpp:49): one sample per pixel per iteration, accumulated into the
+   film in iteration order.  reset != 0 clears the film first (Output's
+   `reset`, pathtracer.cu:2507).  Returns after the GPU has finished. */
+int caster_render(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset);
+
+/* Same, but only enqueues the work on the renderer's stream (no host
+   synchronisation); pair with caster_sync. */
+int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset);
+int caster_sync(caster_renderer* r);
+
+/* Replaces Output + the D2H copy (pathtracer.cu:2502-2517,
+   CudaRender.cpp:55).  mode 0: linear mean (sum / iterations rendered);
+   mode 1: tonemapped as Output does (filmic or gamma per the scene's camera);
+   mode 2: the raw accumulated sum.  `rgb` is host memory, W*H*3 floats. */
+int caster_read_film(caster_renderer* r, float* rgb, int mode);
+
+/* Same into DEVICE memory owned by the caller (the reference's `float3*
+   output` is a device pointer too); used to hand the film to RCCL. */
+int caster_read_film_device(caster_renderer* r, float* rgb_device, int mode);
+
+/* Adds `n_iters` to the iteration count and `sum_device` (W*H*3 floats on this
+   renderer's device) to the film: merges a film reduced from other GPUs. */
+int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t n_iters);
+
+/* Parity hook (no counterpart in the reference): primitive id, in BVH leaf
+   order, hit by the camera ray of every pixel for `iter`; -1 on a miss. */
+int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids);
+
+int caster_get_stats(caster_renderer* r, caster_stats* out);
+int caster_reset_stats(caster_renderer* r);
+uint32_t caster_iterations(const caster_renderer* r);
+
+/* Replaces EndRender (pathtracer.cu:2683-2689); frees everything. */
+void caster_end(caster_renderer* r);
+
+/* Message of the last failed call on this thread. */
+const char* caster_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,45 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def caster():
+    """The product package (its directory name is not a Python identifier)."""
+    return importlib.import_module("cuda-pathtracer_amd")
+
+
+# name -> (generator, kwargs): small versions of the benchmark scenes
+SMALL_SCENES = {
+    "cornell_ao": dict(name="cornell_ao", width=96, height=96),
+    "cornell_pt": dict(name="cornell_pt", width=96, height=96),
+    "cornell_vpt": dict(name="cornell_vpt", width=96, height=96, depth=8),
+    "knot_pt": dict(name="knot_pt", width=96, height=96, detail=0.08),
+    "stairs_pt": dict(name="stairs_pt", width=128, height=72, detail=0.08),
+    "car_pt": dict(name="car_pt", width=128, height=72, detail=0.01),
+    "car_env": dict(name="car_pt", width=128, height=72, detail=0.01, env=True),
+    "odd_size": dict(name="cornell_pt", width=70, height=45),
+}
+
+
+@pytest.fixture(scope="session")
+def scenes(tmp_path_factory):
+    import gen_scenes
+    base = tmp_path_factory.mktemp("scenes")
+    out = {}
+    for key, kw in SMALL_SCENES.items():
+        kw = dict(kw)
+        name = kw.pop("name")
+        out[key] = gen_scenes.generate(str(base / key), name, **kw)
+    return out
