@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s (and Mrays/s) of path tracing + MIS on the
+bmw-m6 stand-in scene at 1920x1080, at 1/2/4/8 MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" is one batch of `--spp-per-step` samples per pixel over the whole
+frame through the wavefront renderer (generate -> [extend -> shade ->
+shadow/probe]* -> finish), inputs resident in HBM.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank renders its own, disjoint
+iterations of the full frame (weak scaling: per-GPU work fixed) and the films
+are summed onto rank 0 with one RCCL reduce inside the timed region.
+
+Rank 0 prints one JSON line.  `roofline` prices the dominant kernel against
+HBM bandwidth with ALGORITHMIC bytes (32 B per BVH node visited + 36 B per
+triangle tested + 16/32 B per sphere/line, plus the ray/hit records the kernel
+itself moves), the per-ray visit counts being those of the reference's own
+traversal order, counted by the CPU oracle on a sample of the same workload.
+`cpu_baseline` is that oracle (a transcription of the reference integrators;
+the reference itself does not compile) timed on this host's cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def scene_path(name, detail, width, height, depth, rank, barrier):
+    """Generates the synthetic scene once per host (rank 0) and returns its path."""
+    import gen_scenes
+    tag = "%s_d%g_%dx%d_m%d" % (name, detail, width, height, depth)
+    base = os.path.join(os.environ.get("CASTER_SCENE_CACHE", "/tmp/caster_scenes_%d" % os.getuid()), tag)
+    path = os.path.join(base, "scene.json")
+    if rank == 0 and not os.path.exists(path):
+        gen_scenes.generate(base + ".tmp%d" % os.getpid(), name, detail, width, height, depth)
+        try:
+            os.rename(base + ".tmp%d" % os.getpid(), base)
+        except OSError:
+            pass  # another process won the race
+    barrier()
+    return path
+
+
+def algorithmic_bytes_per_ray(counts, kind):
+    """SURVEY-defined per-ray traversal bytes from the oracle's visit counts."""
+    rays = counts["rays"][kind]
+    if rays == 0:
+        return 0.0
+    return (32.0 * counts["nodes"][kind] + 36.0 * counts["tris"][kind] + 16.0 * counts["spheres"][kind]
+            + 32.0 * counts["lines"][kind]) / rays
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="car_pt")
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (roofline then uses no counts)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    caster = importlib.import_module("cuda-pathtracer_amd")
+    path = scene_path(a.scene, a.detail, a.width, a.height, a.depth, rank, barrier)
+    scene = caster.Scene(path)
+    spp = a.spp_per_step
+    r = caster.Renderer(scene, local_rank, spp)
+    npix = scene.width * scene.height
+
+    film = torch.empty(npix * 3, dtype=torch.float32, device="cuda:%d" % local_rank) if world > 1 else None
+
+    def first_iter(step):
+        return 1 + (step * world + rank) * spp
+
+    step_no = 0
+    for _ in range(a.warmup):
+        r.render_async(first_iter(step_no), spp, False)
+        step_no += 1
+    r.sync()
+    r.reset_stats()
+    r.render(1, 0, True)          # clear the film and the iteration count
+    r.set_profiling(True)
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r.render_async(first_iter(step_no), spp, False)
+        step_no += 1
+    if world > 1:
+        r.read_film_device(film.data_ptr(), 2)
+        dist.reduce(film, 0)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st = r.stats()
+    kt = r.kernel_times()
+    rays = torch.tensor(st["rays"] + [st["samples"], st["invalid"], st["stack_overflow"]], dtype=torch.float64)
+    if world > 1:
+        rays = rays.to("cuda:%d" % local_rank)
+        dist.all_reduce(rays)
+        rays = rays.cpu()
+    rays = [float(x) for x in rays]
+    total_samples = rays[4]
+    total_rays = sum(rays[:4])
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/s bmw-m6 1080p path+MIS",
+            "value": total_samples / dt / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "mrays_per_s": total_rays / dt / 1e6,
+            "rays": {"extension": rays[0], "shadow": rays[1], "probe": rays[2], "transmittance": rays[3]},
+            "invalid_samples": rays[5],
+            "stack_overflow": rays[6],
+            "config": {
+                "workload": "%s (bmw-m6 stand-in, %d primitives, %d BVH nodes) %dx%d %s maxDepth %d" % (
+                    a.scene, scene.info.n_prims, scene.info.n_nodes, scene.width, scene.height,
+                    caster.INTEGRATOR_NAMES[scene.integrator], scene.info.max_depth),
+                "spp_per_step": spp,
+                "sharding": "spp (disjoint iterations per rank, one film reduce)" if world > 1 else "none",
+            },
+            "kernel_ms": {k: v[0] for k, v in kt.items()},
+            "kernel_launches": {k: v[1] for k, v in kt.items()},
+        }
+        counts = None
+        if not a.no_cpu:
+            import oracle_lib as ol
+            o = ol.Oracle(path)
+            threads = a.cpu_threads or min(os.cpu_count() or 1, 16)
+            c = ol.Counts()
+            # bounded sample: every 8th block of 8 scanlines of the frame, 1 spp
+            rows = [(y, min(y + 8, scene.height)) for y in range(0, scene.height, 64)]
+            t0 = time.perf_counter()
+            for y0, y1 in rows:
+                o.render(1, 1, threads, counts=c, rows=(y0, y1))
+            tc = time.perf_counter() - t0
+            n_cpu = c.samples
+            c1 = ol.Counts()
+            y_mid = scene.height // 2
+            t0 = time.perf_counter()
+            o.render(1, 1, 1, counts=c1, rows=(y_mid, min(y_mid + 4, scene.height)))
+            tc1 = time.perf_counter() - t0
+            counts = c.as_dict()
+            out["cpu_baseline"] = {
+                "value": n_cpu / tc / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+                "sample": "%d samples: 1 spp on every 8th block of 8 scanlines of the same %dx%d frame" % (
+                    n_cpu, scene.width, scene.height),
+                "single_thread_msamples_per_s": c1.samples / tc1 / 1e6,
+                "mrays_per_s": sum(counts["rays"]) / tc / 1e6,
+            }
+        # roofline of the dominant kernel
+        walk = {"extend": 0, "shadow": 1, "probe": 2}
+        dom = max(walk, key=lambda k: kt[k][0])
+        ms, launches = kt[dom]
+        roof = {"bound": "hbm", "kernel": "k_" + dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "avg_launch_ms": ms / max(launches, 1), "launches": launches}
+        if counts is not None and ms > 0:
+            kind = walk[dom]
+            per_ray = algorithmic_bytes_per_ray(counts, kind)
+            record = {"extend": 32 + 16, "shadow": 32 + 4, "probe": 32 + 4 + 16}[dom]
+            # this rank's rays of that kind in the timed region
+            n_rays = st["rays"][kind]
+            achieved = n_rays * (per_ray + record) / (ms * 1e-3) / 1e9
+            roof.update(achieved=achieved, frac=achieved / HBM_PEAK_GBS,
+                        algorithmic_bytes_per_ray=per_ray + record,
+                        rays_per_launch=n_rays / max(launches, 1),
+                        nodes_per_ray=counts["nodes"][kind] / max(counts["rays"][kind], 1),
+                        tris_per_ray=counts["tris"][kind] / max(counts["rays"][kind], 1))
+        else:
+            roof.update(achieved=None, frac=None)
+        out["roofline"] = roof
+        print(json.dumps(out))
+    r.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

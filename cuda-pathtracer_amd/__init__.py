@@ -45,6 +45,13 @@ class Stats(C.Structure):
                 "stack_overflow": self.stack_overflow}
 
 
+KERNEL_CLASSES = ["generate", "extend", "shade", "shadow", "probe", "finish"]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_uint64 * 6)]
+
+
 _lib = None
 
 # every symbol include/caster.h declares
@@ -52,7 +59,7 @@ EXPORTS = [
     "caster_scene_load", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_set_rows",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
     "caster_film_add_device", "caster_primary_ids", "caster_get_stats", "caster_reset_stats",
-    "caster_iterations", "caster_end", "caster_last_error",
+    "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
 ]
 
 
@@ -80,6 +87,8 @@ def lib():
         L.caster_primary_ids.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32)]
         L.caster_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.caster_reset_stats.argtypes = [vp]
+        L.caster_set_profiling.argtypes = [vp, C.c_int]
+        L.caster_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
         L.caster_iterations.argtypes = [vp]
         L.caster_iterations.restype = C.c_uint32
         L.caster_end.argtypes = [vp]
@@ -163,6 +172,15 @@ class Renderer:
         st = Stats()
         _check(lib().caster_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def set_profiling(self, enable=True):
+        _check(lib().caster_set_profiling(self._h, 1 if enable else 0))
+
+    def kernel_times(self):
+        """{class: (total ms, launches)} since profiling was enabled."""
+        kt = KernelTimes()
+        _check(lib().caster_get_kernel_times(self._h, C.byref(kt)))
+        return {n: (kt.ms[i], kt.launches[i]) for i, n in enumerate(KERNEL_CLASSES)}
 
     def reset_stats(self):
         _check(lib().caster_reset_stats(self._h))

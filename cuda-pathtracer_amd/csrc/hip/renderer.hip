@@ -197,6 +197,13 @@ struct caster_renderer {
   uint64_t samples = 0;
   int y0 = 0, y1 = 0;
   int n_cu = 256;
+  // optional per-kernel-class timing with HIP events on the render stream
+  bool profiling = false;
+  struct Timed { int cls; hipEvent_t a, b; };
+  std::vector<Timed> pending_events;
+  std::vector<hipEvent_t> free_events;
+  double class_ms[CASTER_N_KERNEL_CLASSES] = {0};
+  uint64_t class_launches[CASTER_N_KERNEL_CLASSES] = {0};
 };
 
 namespace caster {
@@ -310,6 +317,32 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
 
 static inline LaunchCtx ctx_of(caster_renderer* r) { return LaunchCtx{r->S, r->P, r->stats}; }
 
+static hipEvent_t take_event(caster_renderer* r) {
+  if (!r->free_events.empty()) { hipEvent_t e = r->free_events.back(); r->free_events.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+// Brackets one kernel launch with events when profiling is on.
+struct ScopedTimer {
+  caster_renderer* r; int cls; hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(caster_renderer* r_, int cls_) : r(r_), cls(cls_) {
+    if (r->profiling) { a = take_event(r); b = take_event(r); (void)hipEventRecord(a, r->stream); }
+  }
+  ~ScopedTimer() {
+    if (r->profiling) { (void)hipEventRecord(b, r->stream); r->pending_events.push_back({cls, a, b}); }
+  }
+};
+static void collect_timers(caster_renderer* r) {
+  for (auto& t : r->pending_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { r->class_ms[t.cls] += ms; r->class_launches[t.cls]++; }
+    r->free_events.push_back(t.a);
+    r->free_events.push_back(t.b);
+  }
+  r->pending_events.clear();
+}
+
 // Enqueues one batch of `n` iterations starting at `first`.
 static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   const DevScene& S = r->S;
@@ -320,7 +353,10 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   const int shade_grid = r->n_cu * 16;
   const int gen_grid = (int)std::min<uint32_t>((total + kWave - 1) / kWave, (uint32_t)r->n_cu * 32);
   int cur = 0;
-  hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, r->ext[0], first, n, r->y0, r->y1);
+  {
+    ScopedTimer t(r, CASTER_K_GENERATE);
+    hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, r->ext[0], first, n, r->y0, r->y1);
+  }
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, r->ext[0].count, total);
   hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                      (const uint32_t*)nullptr, r->ext[1].count, r->shadow.count, r->probe.count, 0u);
@@ -328,13 +364,25 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   auto bounce = [&](int b) {
     RayQueue& q = r->ext[cur];
     ShadeQueues out{r->ext[cur ^ 1], r->shadow, r->probe};
-    hipLaunchKernelGGL(k_extend, dim3(walk_grid), dim3(kWave), 0, st, L, q);
-    if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
-    else if (S.integrator == IT_VPT) hipLaunchKernelGGL(k_shade_vpt, dim3(walk_grid), dim3(kWave), 0, st, L, q, out);
-    else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
+    {
+      ScopedTimer t(r, CASTER_K_EXTEND);
+      hipLaunchKernelGGL(k_extend, dim3(walk_grid), dim3(kWave), 0, st, L, q);
+    }
+    {
+      ScopedTimer t(r, CASTER_K_SHADE);
+      if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
+      else if (S.integrator == IT_VPT) hipLaunchKernelGGL(k_shade_vpt, dim3(walk_grid), dim3(kWave), 0, st, L, q, out);
+      else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
+    }
     if (S.integrator != IT_VPT) {
-      hipLaunchKernelGGL(k_shadow, dim3(walk_grid), dim3(kWave), 0, st, L, r->shadow);
-      if (S.integrator == IT_PT) hipLaunchKernelGGL(k_probe, dim3(walk_grid), dim3(kWave), 0, st, L, r->probe);
+      {
+        ScopedTimer t(r, CASTER_K_SHADOW);
+        hipLaunchKernelGGL(k_shadow, dim3(walk_grid), dim3(kWave), 0, st, L, r->shadow);
+      }
+      if (S.integrator == IT_PT) {
+        ScopedTimer t(r, CASTER_K_PROBE);
+        hipLaunchKernelGGL(k_probe, dim3(walk_grid), dim3(kWave), 0, st, L, r->probe);
+      }
     }
     // the camera queue also holds slots outside the image / row range: count only live rays
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)q.count,
@@ -360,7 +408,10 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
       bounce(b);
     }
   }
-  hipLaunchKernelGGL(k_finish, dim3(r->n_cu * 8), dim3(256), 0, st, L, r->acc, n, r->y0, r->y1);
+  {
+    ScopedTimer t(r, CASTER_K_FINISH);
+    hipLaunchKernelGGL(k_finish, dim3(r->n_cu * 8), dim3(256), 0, st, L, r->acc, n, r->y0, r->y1);
+  }
   HIPCHECK(hipGetLastError());
   return CASTER_OK;
 }
@@ -400,6 +451,8 @@ void caster_end(caster_renderer* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+  for (auto& t : r->pending_events) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (hipEvent_t e : r->free_events) (void)hipEventDestroy(e);
   for (void* p : r->allocs) (void)hipFree(p);
   delete r;
 }
@@ -446,6 +499,24 @@ int caster_sync(caster_renderer* r) {
   if (!r) return fail(CASTER_ERR_ARG, "caster_sync: null renderer");
   HIPCHECK(hipSetDevice(r->device));
   HIPCHECK(hipStreamSynchronize(r->stream));
+  collect_timers(r);
+  return CASTER_OK;
+}
+
+int caster_set_profiling(caster_renderer* r, int enable) {
+  if (!r) return fail(CASTER_ERR_ARG, "caster_set_profiling: null renderer");
+  int rc = caster_sync(r);
+  if (rc) return rc;
+  r->profiling = enable != 0;
+  for (int i = 0; i < CASTER_N_KERNEL_CLASSES; ++i) { r->class_ms[i] = 0; r->class_launches[i] = 0; }
+  return CASTER_OK;
+}
+
+int caster_get_kernel_times(caster_renderer* r, caster_kernel_times* out) {
+  if (!r || !out) return fail(CASTER_ERR_ARG, "caster_get_kernel_times: null argument");
+  int rc = caster_sync(r);
+  if (rc) return rc;
+  for (int i = 0; i < CASTER_N_KERNEL_CLASSES; ++i) { out->ms[i] = r->class_ms[i]; out->launches[i] = r->class_launches[i]; }
   return CASTER_OK;
 }
 

@@ -98,6 +98,20 @@ int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t
    order, hit by the camera ray of every pixel for `iter`; -1 on a miss. */
 int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids);
 
+/* Per-kernel-class device time, measured with HIP events recorded on the
+   renderer's own stream around every launch (no counterpart in the
+   reference, which measures nothing).  Enabling resets the totals. */
+enum {
+  CASTER_K_GENERATE = 0, CASTER_K_EXTEND, CASTER_K_SHADE, CASTER_K_SHADOW, CASTER_K_PROBE, CASTER_K_FINISH,
+  CASTER_N_KERNEL_CLASSES
+};
+typedef struct caster_kernel_times {
+  double ms[CASTER_N_KERNEL_CLASSES];
+  uint64_t launches[CASTER_N_KERNEL_CLASSES];
+} caster_kernel_times;
+int caster_set_profiling(caster_renderer* r, int enable);
+int caster_get_kernel_times(caster_renderer* r, caster_kernel_times* out);
+
 int caster_get_stats(caster_renderer* r, caster_stats* out);
 int caster_reset_stats(caster_renderer* r);
 uint32_t caster_iterations(const caster_renderer* r);

@@ -1330,10 +1330,17 @@ void oracle_info(const oracle_ctx* c, int* o) {
 
 int oracle_render(oracle_ctx* c, uint32_t first_iter, uint32_t n_iter, int threads, float* acc,
                   oracle_counts* counts) {
+  return oracle_render_rows(c, first_iter, n_iter, threads, 0, c->cx.scene.height, acc, counts);
+}
+
+int oracle_render_rows(oracle_ctx* c, uint32_t first_iter, uint32_t n_iter, int threads, int y0, int y1, float* acc,
+                       oracle_counts* counts) {
   const Ctx& cx = c->cx;
-  const uint32_t W = cx.scene.width, H = cx.scene.height;
+  const uint32_t W = cx.scene.width;
+  if (y0 < 0 || y1 > cx.scene.height || y0 > y1) return 1;
+  const uint32_t H = (uint32_t)y1;
   if (threads <= 0) threads = 1;
-  std::atomic<uint32_t> next_row{0};
+  std::atomic<uint32_t> next_row{(uint32_t)y0};
   std::vector<Counters> ks(threads);
   auto work = [&](int tid) {
     Counters& k = ks[tid];

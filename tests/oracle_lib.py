@@ -40,6 +40,8 @@ def lib():
         L.oracle_last_error.restype = C.c_char_p
         L.oracle_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.oracle_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, fp, C.POINTER(Counts)]
+        L.oracle_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, fp,
+                                         C.POINTER(Counts)]
         L.oracle_tonemap.argtypes = [fp, fp, C.c_int, C.c_int]
         L.oracle_primary_ids.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
         L.oracle_primary_ids_bruteforce.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
@@ -89,13 +91,17 @@ class Oracle:
         except Exception:
             pass
 
-    def render(self, first_iter, n_iter, threads=0, acc=None, counts=None):
+    def render(self, first_iter, n_iter, threads=0, acc=None, counts=None, rows=None):
         """Returns the accumulated sum image (H, W, 3), row 0 = bottom scanline."""
         if threads <= 0:
             threads = min(os.cpu_count() or 1, 64)
         if acc is None:
             acc = np.zeros((self.height, self.width, 3), np.float32)
-        self.L.oracle_render(self.h, first_iter, n_iter, threads, _fp(acc), C.byref(counts) if counts is not None else None)
+        y0, y1 = rows if rows is not None else (0, self.height)
+        rc = self.L.oracle_render_rows(self.h, first_iter, n_iter, threads, y0, y1, _fp(acc),
+                                       C.byref(counts) if counts is not None else None)
+        if rc != 0:
+            raise ValueError("bad row range")
         return acc
 
     def tonemap(self, mean, filmic=True):
