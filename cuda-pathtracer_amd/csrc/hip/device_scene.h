@@ -7,9 +7,10 @@
 // by-value parameter block of pointers into 16-byte-aligned float4 arrays laid
 // out for what each stage reads:
 //
-//   nodes   4 x float4 per inner node: both children's boxes and references
-//           (one 64-byte fetch decides two box tests; the reference fetches a
-//           node, tests its own box, then fetches each child)
+//   nodes   8 x float4 per 4-wide inner node: lo.x[4] lo.y[4] lo.z[4] hi.x[4]
+//           hi.y[4] hi.z[4] child-ref[4] (pad) -- one 128-byte fetch decides
+//           four box tests; the reference fetches a 40-byte node, tests its
+//           own box, then fetches each of two children
 //   isect   3 x float4 per primitive: only what the ray/primitive test reads
 //   shade   8 x float4 per primitive: normals, uvs, tangents, indices; read
 //           once per accepted hit by the shade stage
@@ -21,7 +22,7 @@
 
 namespace caster {
 
-constexpr int kNodeF4 = 4;
+constexpr int kNodeF4 = 8;
 constexpr int kIsectF4 = 3;
 constexpr int kShadeF4 = 8;
 constexpr int kLightF4 = 6;

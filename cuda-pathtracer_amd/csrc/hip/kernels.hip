@@ -20,7 +20,10 @@
 namespace caster {
 
 constexpr int kWave = 64;
-constexpr int kStackDepth = 32;
+constexpr int kLdsDepth = 16;     // traversal-stack entries per lane kept in LDS
+constexpr int kSpillDepth = 48;   // further entries in a per-lane column in HBM
+constexpr uint32_t kChunk = 256;  // rays a wavefront claims from a queue per atomic
+constexpr int kRefillIdle = 16;   // refill a wavefront once this many lanes are idle
 
 // ------------------------------------------------------------------ vectors
 struct V3 { float x, y, z; };
@@ -192,16 +195,15 @@ __device__ inline bool box_test(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float sc
   float tyFar = (hi.y - o.y) * inv.y;
   float tzNear = (lo.z - o.z) * inv.z;
   float tzFar = (hi.z - o.z) * inv.z;
-  using fps::fmax_;
-  using fps::fmin_;
-  float tNear = fmax_(fmax_(fmin_(txNear, txFar), fmin_(tyNear, tyFar)), fmin_(tzNear, tzFar));
-  float tFar = fmin_(fmin_(fmax_(txNear, txFar), fmax_(tyNear, tyFar)), fmax_(tzNear, tzFar));
+  // v_min_f32 / v_max_f32 drop a NaN operand exactly as fps::fmin_/fmax_ do;
+  // they may differ in the sign of a zero result, which no comparison below sees.
+  float tNear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(txNear, txFar), __builtin_fminf(tyNear, tyFar)),
+                                __builtin_fminf(tzNear, tzFar));
+  float tFar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(txNear, txFar), __builtin_fmaxf(tyNear, tyFar)),
+                               __builtin_fmaxf(tzNear, tzFar));
   tFar *= scale;
   tn = tNear;
-  if (tFar <= 0.00001f) return false;
-  if (tNear > tFar) return false;
-  if (tNear > tmax) return false;
-  return true;
+  return !(tFar <= 0.00001f) && !(tNear > tFar) && !(tNear > tmax);
 }
 
 struct Hit {
@@ -298,69 +300,115 @@ __device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, float max
   }
 }
 
-// Closest-hit (ANY=false) or any-hit (ANY=true) walk.  Children are visited
-// nearest first; a deferred child carries its entry distance so that it is
-// dropped at pop time once a closer hit is known, which is the test the
-// reference makes when it reaches that node (pathtracer.cu:231-232).  Among
-// hits at equal distance the higher primitive index wins, as in the
-// reference's in-order leaf scan with its `t <= tmax` acceptance.
+// Traversal stack: (child reference, entry distance) pairs.  The first
+// kLdsDepth entries of a lane live in LDS, lane-strided so that one wavefront
+// push or pop is a single conflict-free 8-byte ds access; deeper entries go to
+// a per-lane column in HBM (lane-strided too, so a wavefront's spill is one
+// coalesced store).
+struct WalkAux {
+  uint32_t* work;         // next unclaimed ray of the queue being traced
+  uint2* spill;           // kSpillDepth x spill_stride entries
+  uint32_t spill_stride;  // lanes in the launch grid
+};
+struct Stack {
+  uint2 (*lds)[kWave];
+  uint2* spill;  // this lane's column
+  uint32_t stride;
+  int sp;
+};
+__device__ inline bool stack_push(Stack& s, uint32_t lane, int ref, float tn) {
+  uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
+  if (s.sp < kLdsDepth) s.lds[s.sp][lane] = e;
+  else if (s.sp < kLdsDepth + kSpillDepth) s.spill[(size_t)(s.sp - kLdsDepth) * s.stride] = e;
+  else return false;
+  ++s.sp;
+  return true;
+}
+// Next deferred child that can still hold a closer hit: an entry whose entry
+// distance exceeds the current tmax is dropped, which is the test the
+// reference makes when it reaches that node (pathtracer.cu:231-232,
+// bbox.h:95).  kRefEmpty when nothing is left.
+__device__ inline int stack_next(Stack& s, uint32_t lane, float tmax) {
+  while (s.sp > 0) {
+    --s.sp;
+    uint2 e = s.sp < kLdsDepth ? s.lds[s.sp][lane] : s.spill[(size_t)(s.sp - kLdsDepth) * s.stride];
+    if (!(__uint_as_float(e.y) > tmax)) return (int)e.x;
+  }
+  return kRefEmpty;
+}
+
+// One 4-wide node: four slab tests, the children that pass sorted nearest
+// first; the nearest is returned, the others are deferred.
+__device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float tmax, Stack& st, uint32_t lane,
+                                unsigned long long* overflow) {
+  const float4* n = S.nodes + (size_t)cur * kNodeF4;
+  float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
+  int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+  float k0, k1, k2, k3;
+  bool h0 = box_test(v3(lx.x, ly.x, lz.x), v3(hx.x, hy.x, hz.x), o, inv, tmax, S.box_scale, k0) && r0 != kRefEmpty;
+  bool h1 = box_test(v3(lx.y, ly.y, lz.y), v3(hx.y, hy.y, hz.y), o, inv, tmax, S.box_scale, k1) && r1 != kRefEmpty;
+  bool h2 = box_test(v3(lx.z, ly.z, lz.z), v3(hx.z, hy.z, hz.z), o, inv, tmax, S.box_scale, k2) && r2 != kRefEmpty;
+  bool h3 = box_test(v3(lx.w, ly.w, lz.w), v3(hx.w, hy.w, hz.w), o, inv, tmax, S.box_scale, k3) && r3 != kRefEmpty;
+  int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+  if (nh == 0) return stack_next(st, lane, tmax);
+  k0 = h0 ? k0 : INFINITY; k1 = h1 ? k1 : INFINITY; k2 = h2 ? k2 : INFINITY; k3 = h3 ? k3 : INFINITY;
+#define CASTER_CSWAP(ka, ra, kb, rb)        \
+  if (kb < ka) {                             \
+    float tk_ = ka; ka = kb; kb = tk_;       \
+    int tr_ = ra; ra = rb; rb = tr_;         \
+  }
+  CASTER_CSWAP(k0, r0, k1, r1)
+  CASTER_CSWAP(k2, r2, k3, r3)
+  CASTER_CSWAP(k0, r0, k2, r2)
+  CASTER_CSWAP(k1, r1, k3, r3)
+  CASTER_CSWAP(k1, r1, k2, r2)
+#undef CASTER_CSWAP
+  bool ok = true;
+  if (nh > 3) ok &= stack_push(st, lane, r3, k3);
+  if (nh > 2) ok &= stack_push(st, lane, r2, k2);
+  if (nh > 1) ok &= stack_push(st, lane, r1, k1);
+  if (!ok) atomicAdd(overflow, 1ull);
+  return r0;
+}
+
+// Tests the primitives of the leaf starting at `i`.  Among hits at equal
+// distance the higher primitive index wins, as in the reference's in-order
+// scan with its `t <= tmax` acceptance.  ANY: returns at the first hit.
 template <bool ANY>
-__device__ inline bool traverse(const DevScene& S, V3 o, V3 d, float tmin, float tmax, Hit& hit,
-                                int (*s_ref)[kWave], float (*s_tn)[kWave], unsigned long long* overflow) {
+__device__ inline bool leaf_step(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, Hit& hit) {
+  bool last;
+  do {
+    float t, b1, b2;
+    if (prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last)) {
+      if (ANY) return true;
+      if (t < hit.t || i > hit.prim) { hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2; }
+    }
+    ++i;
+  } while (!last);
+  return false;
+}
+
+// Closest-hit (ANY=false) or any-hit (ANY=true) walk of one ray by one lane.
+template <bool ANY>
+__device__ inline bool traverse(const DevScene& S, V3 o, V3 d, float tmin, float tmax, Hit& hit, Stack& st,
+                                unsigned long long* overflow) {
   const uint32_t lane = threadIdx.x & 63u;
   V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
   float maxD = maxcomp(vabs(d));
   hit.prim = -1;
   hit.t = tmax;
   hit.b1 = hit.b2 = 0.f;
-  if (S.n_nodes == 0) return false;
-  int sp = 0;
-  int cur = 0;
-  for (;;) {
+  st.sp = 0;
+  int cur = S.n_nodes ? 0 : kRefEmpty;
+  while (cur != kRefEmpty) {
     if (cur >= 0) {
-      const float4* n = S.nodes + (size_t)cur * kNodeF4;
-      float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-      float tn0, tn1;
-      bool h0 = box_test(v3(n0), v3(n1), o, inv, hit.t, S.box_scale, tn0);
-      bool h1 = box_test(v3(n2), v3(n3), o, inv, hit.t, S.box_scale, tn1);
-      int c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w);
-      if (h0 && h1) {
-        int nearc = c0, farc = c1;
-        float fart = tn1;
-        if (tn1 < tn0) { nearc = c1; farc = c0; fart = tn0; }
-        if (sp < kStackDepth) {
-          s_ref[sp][lane] = farc;
-          s_tn[sp][lane] = fart;
-          ++sp;
-        } else {
-          atomicAdd(overflow, 1ull);
-        }
-        cur = nearc;
-        continue;
-      }
-      if (h0) { cur = c0; continue; }
-      if (h1) { cur = c1; continue; }
-    } else if (cur != kRefEmpty) {
-      int i = ~cur;
-      bool last;
-      do {
-        float t, b1, b2;
-        if (prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last)) {
-          if (ANY) return true;
-          // t <= hit.t here; at equal distance the higher index wins
-          if (t < hit.t || i > hit.prim) { hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2; }
-        }
-        ++i;
-      } while (!last);
-    }
-    // pop
-    for (;;) {
-      if (sp == 0) return hit.prim >= 0;
-      --sp;
-      cur = s_ref[sp][lane];
-      if (!(s_tn[sp][lane] > hit.t)) break;
+      cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
+    } else {
+      if (leaf_step<ANY>(S, ~cur, o, d, maxD, tmin, hit)) return true;
+      cur = stack_next(st, lane, hit.t);
     }
   }
+  return hit.prim >= 0;
 }
 
 // ----------------------------------------------------------------- kernels
@@ -410,36 +458,102 @@ __global__ __launch_bounds__(kWave) void k_generate(LaunchCtx L, RayQueue q, uin
 
 __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 
-// Closest hit for every ray of a queue; the hit goes back into the queue
-// entry (coalesced), to be consumed by the shade stage.
-__global__ __launch_bounds__(kWave) void k_extend(LaunchCtx L, RayQueue q) {
-  __shared__ int s_ref[kStackDepth][kWave];
-  __shared__ float s_tn[kStackDepth][kWave];
+// Traces every ray of a queue with persistent wavefronts.
+//
+// A wavefront claims rays kChunk at a time from the queue's work counter and
+// keeps its 64 lanes fed: when kRefillIdle lanes have finished their rays the
+// idle lanes take the next unclaimed ones, so a long ray does not hold 63 idle
+// lanes hostage.  Between refills the lanes advance in two phases, all lanes
+// that stand at an inner node first (until none does), then all lanes that
+// stand at a leaf, so that node code and primitive code are not interleaved
+// lane by lane.
+//   ANY=false: closest hit; (t, prim, b1, b2) goes into the queue entry.
+//   ANY=true:  any hit; an occluded ray clears the pending light-sampled term
+//              of its path.
+template <bool ANY>
+__global__ __launch_bounds__(kWave) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
+  __shared__ uint2 s_stack[kLdsDepth][kWave];
+  const DevScene& S = L.S;
+  const uint32_t lane = threadIdx.x;
   const uint32_t count = *q.count;
-  for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
-    float4 o4 = q.o[idx], d4 = q.d[idx];
-    Hit h;
-    h.t = d4.w; h.prim = -1; h.b1 = h.b2 = 0.f;
-    if (d4.w >= 0.f) traverse<false>(L.S, v3(o4), v3(d4), o4.w, d4.w, h, s_ref, s_tn, &L.stats->stack_overflow);
-    q.hit[idx] = make_float4(h.t, __int_as_float(h.prim), h.b1, h.b2);
-  }
-}
-
-// Any-hit for the light-sample rays: an occluded ray clears the pending
-// light-sampled term of its path.
-__global__ __launch_bounds__(kWave) void k_shadow(LaunchCtx L, RayQueue q) {
-  __shared__ int s_ref[kStackDepth][kWave];
-  __shared__ float s_tn[kStackDepth][kWave];
-  const uint32_t count = *q.count;
-  for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
-    float4 o4 = q.o[idx], d4 = q.d[idx];
-    Hit h;
-    bool occluded = traverse<true>(L.S, v3(o4), v3(d4), o4.w, d4.w, h, s_ref, s_tn, &L.stats->stack_overflow);
-    if (occluded) {
-      int slot = q.slot[idx];
-      float4 px = L.P.pend_x[slot];
-      px.x = 0.f; px.y = 0.f; px.z = 0.f;
-      L.P.pend_x[slot] = px;
+  unsigned long long* overflow = &L.stats->stack_overflow;
+  Stack st{s_stack, aux.spill + (blockIdx.x * kWave + lane), aux.spill_stride, 0};
+  int idx = -1;
+  int cur = kRefEmpty;
+  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 1);
+  float tmin = 0.f, maxD = 1.f;
+  Hit hit;
+  hit.t = 0.f; hit.prim = -1; hit.b1 = hit.b2 = 0.f;
+  bool occluded = false;
+  uint32_t chunk_next = 0, chunk_end = 0;
+  bool more = true;
+  for (;;) {
+    // retire finished rays
+    if (idx >= 0 && cur == kRefEmpty) {
+      if (ANY) {
+        if (occluded) {
+          int slot = q.slot[idx];
+          float4 px = L.P.pend_x[slot];
+          px.x = 0.f; px.y = 0.f; px.z = 0.f;
+          L.P.pend_x[slot] = px;
+        }
+      } else {
+        q.hit[idx] = make_float4(hit.t, __int_as_float(hit.prim), hit.b1, hit.b2);
+      }
+      idx = -1;
+    }
+    // refill idle lanes
+    unsigned long long idle_mask = __ballot(idx < 0);
+    uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+    if (more && n_idle >= (uint32_t)kRefillIdle) {
+      if (chunk_next == chunk_end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(aux.work, kChunk);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= count) {
+          more = false;
+        } else {
+          chunk_next = base;
+          chunk_end = base + kChunk < count ? base + kChunk : count;
+        }
+      }
+      if (more) {
+        uint32_t avail = chunk_end - chunk_next;
+        uint32_t give = avail < n_idle ? avail : n_idle;
+        uint32_t prefix = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+        if (idx < 0 && prefix < give) {
+          idx = (int)(chunk_next + prefix);
+          float4 o4 = q.o[idx], d4 = q.d[idx];
+          o = v3(o4); d = v3(d4);
+          tmin = o4.w;
+          inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+          maxD = maxcomp(vabs(d));
+          hit.t = d4.w; hit.prim = -1; hit.b1 = hit.b2 = 0.f;
+          occluded = false;
+          st.sp = 0;
+          // tmax < 0 marks a camera slot outside the image: nothing to trace
+          cur = (d4.w >= 0.f && S.n_nodes) ? 0 : kRefEmpty;
+        }
+        chunk_next += give;
+      }
+    }
+    if (!__any(idx >= 0)) {
+      if (!more) break;
+      continue;
+    }
+    // phase 1: inner nodes
+    while (__any(cur >= 0)) {
+      if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
+    }
+    // phase 2: leaves
+    if (cur != kRefEmpty) {
+      bool found = leaf_step<ANY>(S, ~cur, o, d, maxD, tmin, hit);
+      if (ANY && found) {
+        occluded = true;
+        cur = kRefEmpty;
+      } else {
+        cur = stack_next(st, lane, hit.t);
+      }
     }
   }
 }
@@ -1094,20 +1208,19 @@ __global__ __launch_bounds__(kWave) void k_shade_pt(LaunchCtx L, RayQueue cur, S
   }
 }
 
-// BSDF-sampled direct light (pathtracer.cu:949-983): closest hit along the
-// sampled direction; an emitter (or the environment on a miss) contributes
+// BSDF-sampled direct light (pathtracer.cu:949-983), after the probe rays have
+// been traced: an emitter hit (or the environment on a miss) contributes
 // weight * fr * Le * |cos| / pdf into the path's pending term.
-__global__ __launch_bounds__(kWave) void k_probe(LaunchCtx L, RayQueue q) {
-  __shared__ int s_ref[kStackDepth][kWave];
-  __shared__ float s_tn[kStackDepth][kWave];
+__global__ __launch_bounds__(kWave) void k_probe_resolve(LaunchCtx L, RayQueue q) {
   const DevScene& S = L.S;
   const uint32_t count = *q.count;
   for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
-    float4 o4 = q.o[idx], d4 = q.d[idx];
+    float4 o4 = q.o[idx], d4 = q.d[idx], h4 = q.hit[idx];
     int slot = q.slot[idx];
     V3 pos = v3(o4), out = v3(d4);
     Hit h;
-    bool found = traverse<false>(S, pos, out, o4.w, d4.w, h, s_ref, s_tn, &L.stats->stack_overflow);
+    h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+    bool found = h.prim >= 0;
     float4 py = L.P.pend_y[slot];
     V3 fr = v3(py);
     float pdf = py.w;
@@ -1145,7 +1258,7 @@ __global__ __launch_bounds__(kWave) void k_probe(LaunchCtx L, RayQueue q) {
 }
 
 // Probe rays that were never issued leave (fr,pdf) = 0 in pend_y, which reads
-// as a zero contribution; issued ones are always overwritten by k_probe.
+// as a zero contribution; issued ones are always overwritten by k_probe_resolve.
 
 // One vertex of Ao() (pathtracer.cu:841-868).
 __global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, ShadeQueues out) {
@@ -1218,15 +1331,15 @@ constexpr int kMaxCrossings = 1024;
 
 // Tr() (pathtracer.cu:307-331): transmittance along a shadow ray, marching
 // through index-matched boundaries; an opaque hit gives zero.
-__device__ V3 transmittance(const DevScene& S, V3 o, V3 d, float tmin, float tmax, int medium,
-                            int (*s_ref)[kWave], float (*s_tn)[kWave], Stats* stats, uint32_t& segs) {
+__device__ V3 transmittance(const DevScene& S, V3 o, V3 d, float tmin, float tmax, int medium, Stack& st,
+                            Stats* stats, uint32_t& segs) {
   V3 tr = v3(1, 1, 1);
   float remaining = tmax;
   float seg_tmax = tmax;
   for (int guard = 0; guard < kMaxCrossings; ++guard) {
     Hit h;
     ++segs;
-    bool found = traverse<false>(S, o, d, tmin, seg_tmax, h, s_ref, s_tn, &stats->stack_overflow);
+    bool found = traverse<false>(S, o, d, tmin, seg_tmax, h, st, &stats->stack_overflow);
     int mat = -1, med_in = -1, med_out = -1;
     V3 n = v3(0, 0, 0);
     if (found) {
@@ -1251,9 +1364,9 @@ __device__ V3 transmittance(const DevScene& S, V3 o, V3 d, float tmin, float tma
 // One event of Volpath() (pathtracer.cu:1040-1223).  Shadow transmittance and
 // the BSDF-sampled light probe are walked inside this kernel; only the
 // continuation ray goes back through the extend stage.
-__global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, ShadeQueues out) {
-  __shared__ int s_ref[kStackDepth][kWave];
-  __shared__ float s_tn[kStackDepth][kWave];
+__global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, ShadeQueues out, WalkAux aux) {
+  __shared__ uint2 s_stack[kLdsDepth][kWave];
+  Stack st{s_stack, aux.spill + (blockIdx.x * kWave + threadIdx.x), aux.spill_stride, 0};
   const DevScene& S = L.S;
   const PathState& P = L.P;
   const uint32_t count = *cur.count;
@@ -1319,7 +1432,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
             float ltmax, lightPdf, choicePdf;
             sample_one_light(S, rng, samplePos, radiance, ldir, ltmax, lightPdf, choicePdf);
             V3 tr = is_black(radiance) ? v3(1, 1, 1)
-                                       : transmittance(S, samplePos, ldir, S.epsilon, ltmax, rmed, s_ref, s_tn, L.stats, n_tr);
+                                       : transmittance(S, samplePos, ldir, S.epsilon, ltmax, rmed, st, L.stats, n_tr);
             // Medium::Phase / SamplePhase (medium.h:146-186)
             float phase;
             if (med.g == 0) phase = ONE_OVER_FOUR_PI;
@@ -1376,7 +1489,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
                   V3 fr;
                   float samplePdf;
                   eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
-                  V3 tr = transmittance(S, pos, ldir, S.epsilon, ltmax, rmed, s_ref, s_tn, L.stats, n_tr);
+                  V3 tr = transmittance(S, pos, ldir, S.epsilon, ltmax, rmed, st, L.stats, n_tr);
                   float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
                   Ld = Ld + weight * tr * fr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
                 }
@@ -1388,7 +1501,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
                 if (!is_black(mfr) && mpdf != 0) {
                   Hit lh;
                   ++n_probe;
-                  bool found = traverse<false>(S, pos, mo, S.epsilon, INFINITY, lh, s_ref, s_tn, &L.stats->stack_overflow);
+                  bool found = traverse<false>(S, pos, mo, S.epsilon, INFINITY, lh, st, &L.stats->stack_overflow);
                   if (found) {
                     int light = __float_as_int(S.shade[(size_t)lh.prim * kShadeF4 + 6].y);
                     uint32_t type = __float_as_uint(S.isect[(size_t)lh.prim * kIsectF4 + 2].w) & kPrimTypeMask;
@@ -1532,7 +1645,8 @@ __global__ void k_gather_ids(LaunchCtx L, RayQueue q, int32_t* ids) {
 // Adds the three queue lengths of a finished bounce to the ray statistics and
 // clears the queues that the next shade pass appends to.
 __global__ void k_roll(Stats* st, const uint32_t* n_ext, const uint32_t* n_shadow, const uint32_t* n_probe,
-                       uint32_t* clear0, uint32_t* clear1, uint32_t* clear2, uint32_t ext_override) {
+                       uint32_t* clear0, uint32_t* clear1, uint32_t* clear2, uint32_t ext_override, uint32_t* work3) {
+  if (work3) { work3[0] = 0; work3[1] = 0; work3[2] = 0; }
   if (ext_override) st->rays[0] += ext_override;
   else if (n_ext) st->rays[0] += *n_ext;
   if (n_shadow) st->rays[1] += *n_shadow;

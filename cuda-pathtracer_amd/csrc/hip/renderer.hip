@@ -54,35 +54,71 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
   A.shade.assign(np * kShadeF4, make_float4(0, 0, 0, 0));
   std::vector<uint32_t> tail(np, 0);
   for (size_t i = 0; i < np; ++i) tail[i] = (uint32_t)sc.prims[i].type & kPrimTypeMask;
-  // Inner nodes only: each carries both children's boxes (bvh.h:19-29 keeps a
-  // node's own box instead).  Leaf ranges end at the primitive flagged "last".
-  std::vector<int> dev_index(sc.nodes.size(), -1);
-  int n_inner = 0;
-  for (size_t i = 0; i < sc.nodes.size(); ++i) if (!sc.nodes[i].leaf) dev_index[i] = n_inner++;
-  auto child_ref = [&](int host) {
+  // The binary tree of the host build is collapsed into 4-wide nodes: a node's
+  // child with the largest box that is itself an inner node is replaced by its
+  // two children until four children are held.  A ray reaches a leaf exactly
+  // when that leaf's own box test passes (a box that passes implies that every
+  // enclosing box passes, because the slab test is monotone in the box), so
+  // dropping intermediate boxes changes the work, not the result.  Leaf ranges
+  // end at the primitive flagged "last".
+  auto leaf_ref = [&](int host) {
     const Node& n = sc.nodes[host];
-    if (!n.leaf) return dev_index[host];
     if (n.start < 0) return kRefEmpty;
     tail[n.end] |= kPrimLastInLeaf;
     return ~n.start;
   };
-  const f3 einf_lo = mk3(INFINITY, INFINITY, INFINITY), einf_hi = mk3(-INFINITY, -INFINITY, -INFINITY);
-  if (!sc.nodes.empty() && sc.nodes[0].leaf) {
-    A.nodes.resize(kNodeF4);
-    A.nodes[0] = mk4(sc.nodes[0].lo, as_float(child_ref(0)));
-    A.nodes[1] = mk4(sc.nodes[0].hi, as_float(kRefEmpty));
-    A.nodes[2] = mk4(einf_lo, 0.f);
-    A.nodes[3] = mk4(einf_hi, 0.f);
-  } else {
-    A.nodes.resize((size_t)n_inner * kNodeF4);
-    for (size_t i = 0; i < sc.nodes.size(); ++i) {
-      if (sc.nodes[i].leaf) continue;
-      int c0 = (int)i + 1, c1 = sc.nodes[i].second;
-      float4* d = &A.nodes[(size_t)dev_index[i] * kNodeF4];
-      d[0] = mk4(sc.nodes[c0].lo, as_float(child_ref(c0)));
-      d[1] = mk4(sc.nodes[c0].hi, as_float(child_ref(c1)));
-      d[2] = mk4(sc.nodes[c1].lo, 0.f);
-      d[3] = mk4(sc.nodes[c1].hi, 0.f);
+  auto box_area = [&](int host) {
+    f3 d = sc.nodes[host].hi - sc.nodes[host].lo;
+    return d.x * d.y + d.y * d.z + d.z * d.x;
+  };
+  struct Work { int host; int dev; };
+  std::vector<Work> todo;
+  auto emit_node = [&]() { A.nodes.resize(A.nodes.size() + kNodeF4, make_float4(0, 0, 0, 0)); return (int)(A.nodes.size() / kNodeF4) - 1; };
+  if (!sc.nodes.empty()) {
+    int root_dev = emit_node();
+    todo.push_back({0, root_dev});
+    // depth-first emission keeps a subtree's nodes close together in memory
+    while (!todo.empty()) {
+      Work w = todo.back();
+      todo.pop_back();
+      int kids[4];
+      int nk = 0;
+      if (sc.nodes[w.host].leaf) {
+        kids[nk++] = w.host;  // a scene whose root is a leaf
+      } else {
+        kids[nk++] = w.host + 1;
+        kids[nk++] = sc.nodes[w.host].second;
+        while (nk < 4) {
+          int best = -1;
+          float best_area = -1.f;
+          for (int k = 0; k < nk; ++k)
+            if (!sc.nodes[kids[k]].leaf && box_area(kids[k]) > best_area) { best_area = box_area(kids[k]); best = k; }
+          if (best < 0) break;
+          int h = kids[best];
+          kids[best] = h + 1;
+          kids[nk++] = sc.nodes[h].second;
+        }
+      }
+      float lo[3][4], hi[3][4];
+      int ref[4];
+      for (int k = 0; k < 4; ++k) {
+        if (k < nk) {
+          const Node& c = sc.nodes[kids[k]];
+          lo[0][k] = c.lo.x; lo[1][k] = c.lo.y; lo[2][k] = c.lo.z;
+          hi[0][k] = c.hi.x; hi[1][k] = c.hi.y; hi[2][k] = c.hi.z;
+          if (c.leaf) ref[k] = leaf_ref(kids[k]);
+          else { ref[k] = emit_node(); todo.push_back({kids[k], ref[k]}); }
+        } else {
+          for (int a = 0; a < 3; ++a) { lo[a][k] = INFINITY; hi[a][k] = -INFINITY; }
+          ref[k] = kRefEmpty;
+        }
+      }
+      float4* d = &A.nodes[(size_t)w.dev * kNodeF4];
+      for (int a = 0; a < 3; ++a) {
+        d[a] = make_float4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+        d[3 + a] = make_float4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+      }
+      d[6] = make_float4(as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]));
     }
   }
   for (size_t i = 0; i < np; ++i) {
@@ -186,7 +222,9 @@ struct caster_renderer {
   DevScene S{};
   PathState P{};
   RayQueue ext[2]{}, shadow{}, probe{};
-  uint32_t* counters = nullptr;  // ext0, ext1, shadow, probe
+  uint32_t* counters = nullptr;  // queue lengths: ext0, ext1, shadow, probe; work counters: 4, 5, 6
+  WalkAux aux{};
+  int walk_grid = 0;
   Stats* stats = nullptr;
   float* acc = nullptr;
   float* film_tmp = nullptr;
@@ -304,7 +342,12 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
   if ((rc = alloc_queue(r, r->ext[0], n, true, r->counters + 0))) return rc;
   if ((rc = alloc_queue(r, r->ext[1], n, true, r->counters + 1))) return rc;
   if ((rc = alloc_queue(r, r->shadow, n, false, r->counters + 2))) return rc;
-  if ((rc = alloc_queue(r, r->probe, n, false, r->counters + 3))) return rc;
+  if ((rc = alloc_queue(r, r->probe, n, true, r->counters + 3))) return rc;
+  // persistent traversal grid: 8 KB of LDS stack per wavefront -> 20 wavefronts per CU
+  r->walk_grid = r->n_cu * 20;
+  r->aux.spill_stride = (uint32_t)r->walk_grid * kWave;
+  if ((rc = dev_alloc(r, &r->aux.spill, (size_t)r->aux.spill_stride * kSpillDepth))) return rc;
+  r->aux.work = r->counters + 4;
   if ((rc = dev_alloc(r, &r->stats, 1))) return rc;
   HIPCHECK(hipMemset(r->stats, 0, sizeof(Stats)));
   size_t npix = (size_t)sc.width * sc.height;
@@ -349,7 +392,8 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   hipStream_t st = r->stream;
   LaunchCtx L = ctx_of(r);
   const uint32_t total = (uint32_t)S.slots_per_iter * n;
-  const int walk_grid = r->n_cu * 10;   // 16 KB of LDS stack per wavefront: 10 wavefronts per CU
+  const int walk_grid = r->walk_grid;
+  auto aux_for = [&](int which) { WalkAux a = r->aux; a.work = r->counters + 4 + which; return a; };
   const int shade_grid = r->n_cu * 16;
   const int gen_grid = (int)std::min<uint32_t>((total + kWave - 1) / kWave, (uint32_t)r->n_cu * 32);
   int cur = 0;
@@ -359,35 +403,37 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   }
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, r->ext[0].count, total);
   hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                     (const uint32_t*)nullptr, r->ext[1].count, r->shadow.count, r->probe.count, 0u);
+                     (const uint32_t*)nullptr, r->ext[1].count, r->shadow.count, r->probe.count, 0u, r->counters + 4);
   const uint32_t live_rays = (uint32_t)S.width * (uint32_t)(r->y1 - r->y0) * n;
   auto bounce = [&](int b) {
     RayQueue& q = r->ext[cur];
     ShadeQueues out{r->ext[cur ^ 1], r->shadow, r->probe};
     {
       ScopedTimer t(r, CASTER_K_EXTEND);
-      hipLaunchKernelGGL(k_extend, dim3(walk_grid), dim3(kWave), 0, st, L, q);
+      hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, q, aux_for(0));
     }
     {
       ScopedTimer t(r, CASTER_K_SHADE);
       if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
-      else if (S.integrator == IT_VPT) hipLaunchKernelGGL(k_shade_vpt, dim3(walk_grid), dim3(kWave), 0, st, L, q, out);
+      else if (S.integrator == IT_VPT)
+        hipLaunchKernelGGL(k_shade_vpt, dim3(walk_grid), dim3(kWave), 0, st, L, q, out, r->aux);
       else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
     }
     if (S.integrator != IT_VPT) {
       {
         ScopedTimer t(r, CASTER_K_SHADOW);
-        hipLaunchKernelGGL(k_shadow, dim3(walk_grid), dim3(kWave), 0, st, L, r->shadow);
+        hipLaunchKernelGGL(k_trace<true>, dim3(walk_grid), dim3(kWave), 0, st, L, r->shadow, aux_for(1));
       }
       if (S.integrator == IT_PT) {
         ScopedTimer t(r, CASTER_K_PROBE);
-        hipLaunchKernelGGL(k_probe, dim3(walk_grid), dim3(kWave), 0, st, L, r->probe);
+        hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, r->probe, aux_for(2));
+        hipLaunchKernelGGL(k_probe_resolve, dim3(shade_grid), dim3(kWave), 0, st, L, r->probe);
       }
     }
     // the camera queue also holds slots outside the image / row range: count only live rays
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)q.count,
                        (const uint32_t*)r->shadow.count, (const uint32_t*)r->probe.count, q.count, r->shadow.count,
-                       r->probe.count, b == 0 ? live_rays : 0u);
+                       r->probe.count, b == 0 ? live_rays : 0u, r->counters + 4);
     cur ^= 1;
   };
   if (S.integrator == IT_AO) {
@@ -575,7 +621,13 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, r->stream, L, r->ext[0], iter, 1u,
                      0, r->S.height);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->ext[0].count, total);
-  hipLaunchKernelGGL(k_extend, dim3(r->n_cu * 10), dim3(kWave), 0, r->stream, L, r->ext[0]);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->counters + 4, 0u);
+  {
+    WalkAux a = r->aux;
+    a.work = r->counters + 4;
+    hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid), dim3(kWave), 0, r->stream, L, r->ext[0], a);
+  }
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->counters + 4, 0u);
   hipLaunchKernelGGL(k_gather_ids, dim3(r->n_cu * 4), dim3(256), 0, r->stream, L, r->ext[0], r->ids);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->ext[0].count, 0u);
   HIPCHECK(hipGetLastError());
