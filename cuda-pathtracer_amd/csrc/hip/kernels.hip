@@ -169,21 +169,6 @@ __device__ inline uint32_t pixel_slot(const DevScene& S, uint32_t px, uint32_t p
   return (tile << 6) | ((py & 7u) << 3) | (px & 7u);
 }
 
-// Append one item per active lane of this wavefront to a queue: one atomic
-// per wavefront, lane offsets from the ballot.
-__device__ inline uint32_t queue_reserve(uint32_t* counter, bool want) {
-  unsigned long long mask = __ballot(want);
-  if (mask == 0) return 0;
-  uint32_t n = (uint32_t)__popcll(mask);
-  uint32_t lane = threadIdx.x & 63u;
-  uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  uint32_t base = 0;
-  int leader = __ffsll((long long)mask) - 1;
-  if ((int)lane == leader) base = atomicAdd(counter, n);
-  base = (uint32_t)__shfl((int)base, leader, 64);
-  return base + prefix;
-}
-
 // --------------------------------------------------------------- traversal
 // Slab test of the reference (bbox.h:75-98): tFar widened by 1+2*gamma(3),
 // rejected when behind the ray, empty, or beyond the current tmax; tmin is
@@ -1066,13 +1051,49 @@ struct ShadeQueues {
   RayQueue probe;   // BSDF-sampled direct-light rays (closest hit + weighting)
 };
 
-__device__ inline void push_ray(const RayQueue& q, bool want, int slot, V3 o, float tmin, V3 d, float tmax) {
-  uint32_t at = queue_reserve(q.count, want);
+// Two-level queue compaction.  A shading wavefront appends the rays it emits,
+// ballot-compacted, to a staging region of its own (no atomics: the cursor is
+// a wave-uniform register), and when it has shaded all its paths it reserves
+// its final range in the shared queue with ONE atomic per queue and copies the
+// region there.  Appending straight to the shared queue costs one same-address
+// atomic per 64 paths per queue, which is what bounded the shade stage before.
+struct StageArea {
+  RayQueue next, shadow, probe;  // o/d/slot arrays of gridDim.x * region_cap entries; count unused
+  uint32_t region_cap;           // entries per wavefront region
+};
+__device__ inline void stage_push(const RayQueue& stage, uint32_t base, uint32_t& n, bool want, int slot, V3 o,
+                                  float tmin, V3 d, float tmax) {
+  unsigned long long mask = __ballot(want);
+  if (mask == 0) return;
+  uint32_t lane = threadIdx.x & 63u;
   if (want) {
-    q.o[at] = f4(o, tmin);
-    q.d[at] = f4(d, tmax);
-    q.slot[at] = slot;
+    uint32_t at = base + n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    stage.o[at] = f4(o, tmin);
+    stage.d[at] = f4(d, tmax);
+    stage.slot[at] = slot;
   }
+  n += (uint32_t)__popcll(mask);
+}
+__device__ inline void stage_flush(const RayQueue& stage, uint32_t base, uint32_t n, const RayQueue& fin) {
+  n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+  if (n == 0) return;
+  uint32_t lane = threadIdx.x & 63u;
+  uint32_t off = 0;
+  if (lane == 0) off = atomicAdd(fin.count, n);
+  off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+  for (uint32_t i = lane; i < n; i += kWave) {
+    fin.o[off + i] = stage.o[base + i];
+    fin.d[off + i] = stage.d[base + i];
+    fin.slot[off + i] = stage.slot[base + i];
+  }
+}
+// The rounds (groups of 64 queue entries) wavefront `blockIdx.x` shades: a
+// contiguous range, so that the compacted output keeps the input's order.
+__device__ inline void wave_rounds(uint32_t count, uint32_t& r0, uint32_t& r1) {
+  uint32_t rounds = (count + kWave - 1) / kWave;
+  uint32_t per = (rounds + gridDim.x - 1) / gridDim.x;
+  r0 = blockIdx.x * per;
+  r1 = r0 + per < rounds ? r0 + per : rounds;
 }
 
 // Adds the two direct-light terms left pending by the previous vertex:
@@ -1087,12 +1108,15 @@ __device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li) {
 
 // One vertex of Path() (pathtracer.cu:897-1007) for every path whose
 // extension ray has been traced.
-__global__ __launch_bounds__(kWave) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out) {
+__global__ __launch_bounds__(kWave) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
   const DevScene& S = L.S;
   const PathState& P = L.P;
   const uint32_t count = *cur.count;
-  const uint32_t rounds = (count + kWave - 1) / kWave;
-  for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+  uint32_t r0, r1;
+  wave_rounds(count, r0, r1);
+  const uint32_t sbase = blockIdx.x * stage.region_cap;
+  uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
+  for (uint32_t r = r0; r < r1; ++r) {
     uint32_t idx = r * kWave + threadIdx.x;
     bool active = idx < count;
     int slot = 0;
@@ -1202,10 +1226,14 @@ __global__ __launch_bounds__(kWave) void k_shade_pt(LaunchCtx L, RayQueue cur, S
       P.beta_rng[slot] = f4(beta, rng);
       P.li_flags[slot] = f4(Li, flags);
     }
-    push_ray(out.next, want_next, slot, no, S.epsilon, nd, INFINITY);
-    push_ray(out.shadow, want_shadow, slot, so, S.epsilon, sd, stmax);
-    push_ray(out.probe, want_probe, slot, po, S.epsilon, pd, INFINITY);
+    stage_push(stage.next, sbase, n_next, want_next, slot, no, S.epsilon, nd, INFINITY);
+    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, S.epsilon, sd, stmax);
+    stage_push(stage.probe, sbase, n_probe, want_probe, slot, po, S.epsilon, pd, INFINITY);
   }
+  __syncthreads();  // the copy below reads what other lanes of this wavefront staged
+  stage_flush(stage.next, sbase, n_next, out.next);
+  stage_flush(stage.shadow, sbase, n_shadow, out.shadow);
+  stage_flush(stage.probe, sbase, n_probe, out.probe);
 }
 
 // BSDF-sampled direct light (pathtracer.cu:949-983), after the probe rays have
@@ -1261,12 +1289,15 @@ __global__ __launch_bounds__(kWave) void k_probe_resolve(LaunchCtx L, RayQueue q
 // as a zero contribution; issued ones are always overwritten by k_probe_resolve.
 
 // One vertex of Ao() (pathtracer.cu:841-868).
-__global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, ShadeQueues out) {
+__global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
   const DevScene& S = L.S;
   const PathState& P = L.P;
   const uint32_t count = *cur.count;
-  const uint32_t rounds = (count + kWave - 1) / kWave;
-  for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+  uint32_t r0, r1;
+  wave_rounds(count, r0, r1);
+  const uint32_t sbase = blockIdx.x * stage.region_cap;
+  uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
+  for (uint32_t r = r0; r < r1; ++r) {
     uint32_t idx = r * kWave + threadIdx.x;
     bool want_shadow = false;
     int slot = 0;
@@ -1309,8 +1340,11 @@ __global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, S
         P.li_flags[slot] = f4(Li, flags);
       }
     }
-    push_ray(out.shadow, want_shadow, slot, so, S.epsilon, sd, S.maxDist);
+    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, S.epsilon, sd, S.maxDist);
   }
+  __syncthreads();
+  stage_flush(stage.shadow, sbase, n_shadow, out.shadow);
+  (void)n_next; (void)n_probe;
 }
 
 // ---- volumetric path tracing ------------------------------------------------
@@ -1364,15 +1398,18 @@ __device__ V3 transmittance(const DevScene& S, V3 o, V3 d, float tmin, float tma
 // One event of Volpath() (pathtracer.cu:1040-1223).  Shadow transmittance and
 // the BSDF-sampled light probe are walked inside this kernel; only the
 // continuation ray goes back through the extend stage.
-__global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, ShadeQueues out, WalkAux aux) {
+__global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage, WalkAux aux) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
   Stack st{s_stack, aux.spill + (blockIdx.x * kWave + threadIdx.x), aux.spill_stride, 0};
   const DevScene& S = L.S;
   const PathState& P = L.P;
   const uint32_t count = *cur.count;
-  const uint32_t rounds = (count + kWave - 1) / kWave;
-  uint32_t n_tr = 0, n_probe = 0;
-  for (uint32_t r = blockIdx.x; r < rounds; r += gridDim.x) {
+  uint32_t stat_tr = 0, stat_probe = 0;
+  uint32_t r0, r1;
+  wave_rounds(count, r0, r1);
+  const uint32_t sbase = blockIdx.x * stage.region_cap;
+  uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
+  for (uint32_t r = r0; r < r1; ++r) {
     uint32_t idx = r * kWave + threadIdx.x;
     bool want_next = false;
     int slot = 0;
@@ -1432,7 +1469,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
             float ltmax, lightPdf, choicePdf;
             sample_one_light(S, rng, samplePos, radiance, ldir, ltmax, lightPdf, choicePdf);
             V3 tr = is_black(radiance) ? v3(1, 1, 1)
-                                       : transmittance(S, samplePos, ldir, S.epsilon, ltmax, rmed, st, L.stats, n_tr);
+                                       : transmittance(S, samplePos, ldir, S.epsilon, ltmax, rmed, st, L.stats, stat_tr);
             // Medium::Phase / SamplePhase (medium.h:146-186)
             float phase;
             if (med.g == 0) phase = ONE_OVER_FOUR_PI;
@@ -1489,7 +1526,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
                   V3 fr;
                   float samplePdf;
                   eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
-                  V3 tr = transmittance(S, pos, ldir, S.epsilon, ltmax, rmed, st, L.stats, n_tr);
+                  V3 tr = transmittance(S, pos, ldir, S.epsilon, ltmax, rmed, st, L.stats, stat_tr);
                   float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
                   Ld = Ld + weight * tr * fr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
                 }
@@ -1500,7 +1537,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
                 sample_bsdf(S, m, -rd, nor, uv, dpdu, us, mo, mfr, mpdf);
                 if (!is_black(mfr) && mpdf != 0) {
                   Hit lh;
-                  ++n_probe;
+                  ++stat_probe;
                   bool found = traverse<false>(S, pos, mo, S.epsilon, INFINITY, lh, st, &L.stats->stack_overflow);
                   if (found) {
                     int light = __float_as_int(S.shade[(size_t)lh.prim * kShadeF4 + 6].y);
@@ -1570,16 +1607,19 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
         P.beta_prev[slot] = make_float4(0, 0, 0, __uint_as_float((uint32_t)crossings));
       }
     }
-    push_ray(out.next, want_next, slot, no, S.epsilon, nd, INFINITY);
+    stage_push(stage.next, sbase, n_next, want_next, slot, no, S.epsilon, nd, INFINITY);
   }
+  __syncthreads();
+  stage_flush(stage.next, sbase, n_next, out.next);
+  (void)n_shadow; (void)n_probe;
   // ray statistics: one atomic per wavefront
   for (int off = 32; off > 0; off >>= 1) {
-    n_tr += (uint32_t)__shfl_down((int)n_tr, off, 64);
-    n_probe += (uint32_t)__shfl_down((int)n_probe, off, 64);
+    stat_tr += (uint32_t)__shfl_down((int)stat_tr, off, 64);
+    stat_probe += (uint32_t)__shfl_down((int)stat_probe, off, 64);
   }
   if ((threadIdx.x & 63u) == 0) {
-    if (n_tr) atomicAdd(&L.stats->rays[3], (unsigned long long)n_tr);
-    if (n_probe) atomicAdd(&L.stats->rays[2], (unsigned long long)n_probe);
+    if (stat_tr) atomicAdd(&L.stats->rays[3], (unsigned long long)stat_tr);
+    if (stat_probe) atomicAdd(&L.stats->rays[2], (unsigned long long)stat_probe);
   }
 }
 

@@ -225,6 +225,8 @@ struct caster_renderer {
   uint32_t* counters = nullptr;  // queue lengths: ext0, ext1, shadow, probe; work counters: 4, 5, 6
   WalkAux aux{};
   int walk_grid = 0;
+  StageArea stage{};
+  int shade_grid = 0;
   Stats* stats = nullptr;
   float* acc = nullptr;
   float* film_tmp = nullptr;
@@ -343,6 +345,23 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
   if ((rc = alloc_queue(r, r->ext[1], n, true, r->counters + 1))) return rc;
   if ((rc = alloc_queue(r, r->shadow, n, false, r->counters + 2))) return rc;
   if ((rc = alloc_queue(r, r->probe, n, true, r->counters + 3))) return rc;
+  // shade grid: one wavefront per block, as many as are resident at once; every
+  // wavefront owns a staging region large enough for all paths it can be given
+  {
+    int per_cu = 8;
+    const void* fn = sc.integrator == IT_AO ? (const void*)k_shade_ao
+                     : sc.integrator == IT_VPT ? (const void*)k_shade_vpt : (const void*)k_shade_pt;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (per_cu > 20) per_cu = 20;  // the vpt shade stage indexes the spill area sized for 20 wavefronts per CU
+    r->shade_grid = r->n_cu * per_cu;
+    uint32_t rounds = (n + kWave - 1) / kWave;
+    uint32_t per = (rounds + (uint32_t)r->shade_grid - 1) / (uint32_t)r->shade_grid;
+    r->stage.region_cap = per * kWave;
+    uint32_t cap = r->stage.region_cap * (uint32_t)r->shade_grid;
+    if ((rc = alloc_queue(r, r->stage.next, cap, false, nullptr))) return rc;
+    if ((rc = alloc_queue(r, r->stage.shadow, cap, false, nullptr))) return rc;
+    if ((rc = alloc_queue(r, r->stage.probe, cap, false, nullptr))) return rc;
+  }
   // persistent traversal grid: 8 KB of LDS stack per wavefront -> 20 wavefronts per CU
   r->walk_grid = r->n_cu * 20;
   r->aux.spill_stride = (uint32_t)r->walk_grid * kWave;
@@ -394,7 +413,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   const uint32_t total = (uint32_t)S.slots_per_iter * n;
   const int walk_grid = r->walk_grid;
   auto aux_for = [&](int which) { WalkAux a = r->aux; a.work = r->counters + 4 + which; return a; };
-  const int shade_grid = r->n_cu * 16;
+  const int shade_grid = r->shade_grid;
   const int gen_grid = (int)std::min<uint32_t>((total + kWave - 1) / kWave, (uint32_t)r->n_cu * 32);
   int cur = 0;
   {
@@ -414,10 +433,10 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
     }
     {
       ScopedTimer t(r, CASTER_K_SHADE);
-      if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
+      if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, r->stage);
       else if (S.integrator == IT_VPT)
-        hipLaunchKernelGGL(k_shade_vpt, dim3(walk_grid), dim3(kWave), 0, st, L, q, out, r->aux);
-      else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out);
+        hipLaunchKernelGGL(k_shade_vpt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, r->stage, r->aux);
+      else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, r->stage);
     }
     if (S.integrator != IT_VPT) {
       {
