@@ -63,6 +63,26 @@ EXPORTS = [
 ]
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so.7; libcaster.so asks for the same
+    soname.  A process must hold ONE HIP runtime (two copies each open the GPU and the
+    second finds none), so when torch is installed its copy is loaded first, before
+    libcaster.so resolves the soname.  torch itself is not imported."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Loads libcaster.so (no fallback: the HIP library is the only implementation)."""
     global _lib
@@ -70,6 +90,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build it with `make -C cuda-pathtracer_amd/csrc` "
                               "(or __graft_entry__.build())" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         vp, fp = C.c_void_p, C.POINTER(C.c_float)
         L.caster_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]

@@ -1,0 +1,72 @@
+"""How one image is split over the GPUs of a node, and how the films meet again.
+
+The reference is single-GPU (no NCCL/MPI anywhere in CUDA-PathTracer/tracer/);
+what makes sharding possible is that a sample (pixel, iteration) is a pure
+function of its seed, ``WangHash(pixel) + WangHash(iter)``
+(CUDA-PathTracer/tracer/pathtracer.cu:881), and of the read-only scene.  One
+process drives one GPU; the scene is replicated, and there is no data-path
+collective until the single film exchange at the end:
+
+``spp``   every rank renders the whole frame for its own, disjoint iterations
+          (blocks of ``block`` iterations dealt round-robin); the films are
+          summed onto rank 0 (``torch.distributed.reduce``, RCCL over xGMI on
+          GPUs).  The sum differs from a one-GPU render only by fp32
+          re-association across ranks.
+``tile``  every rank renders all iterations for its own band of scanlines;
+          the other rows of its film stay zero, so the same sum is an exact
+          gather: bit-identical to a one-GPU render.
+
+Nothing here touches a device: the functions take and return plain numbers and
+``torch`` tensors, so the same code runs over ``gloo`` on CPUs in the tests.
+"""
+
+
+def spp_blocks(first_iter, n_iter, block, rank, world):
+    """Contiguous iteration blocks (first, count) of [first_iter, first_iter + n_iter)
+    that `rank` renders: block b of size `block` goes to rank b % world."""
+    if block <= 0 or world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad sharding arguments")
+    out = []
+    b = 0
+    it = first_iter
+    end = first_iter + n_iter
+    while it < end:
+        n = min(block, end - it)
+        if b % world == rank:
+            out.append((it, n))
+        it += n
+        b += 1
+    return out
+
+
+def row_band(height, rank, world, align=8):
+    """Scanlines [y0, y1) of `rank`: contiguous bands whose edges are multiples of
+    `align` (the renderer generates camera rays in 8x8 pixel tiles)."""
+    if world <= 0 or not (0 <= rank < world) or height < 0:
+        raise ValueError("bad sharding arguments")
+    units = (height + align - 1) // align
+    lo = (units * rank) // world
+    hi = (units * (rank + 1)) // world
+    return min(lo * align, height), min(hi * align, height)
+
+
+def reduce_film(film, dist=None, dst=0):
+    """Sums the per-rank accumulated films onto `dst` (in place on that rank).
+    `film` is a flat float32 tensor of W*H*3 on the device the process group's
+    backend works with.  With no process group the film is returned unchanged."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return film
+    dist.reduce(film, dst)
+    return film
+
+
+def total_iterations(n_iter_per_rank, dist=None):
+    """Sum over ranks of the iterations each rendered (needed to divide the summed film)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return n_iter_per_rank
+    import torch
+    t = torch.tensor([float(n_iter_per_rank)], dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t)
+    return int(round(float(t.item())))

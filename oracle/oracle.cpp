@@ -1412,6 +1412,28 @@ int oracle_primary_ids_bruteforce(oracle_ctx* c, uint32_t iter, int32_t* ids) {
   return 0;
 }
 
+void oracle_fps(int op, const float* x, const float* y, int n, float* out) {
+  for (int i = 0; i < n; ++i) {
+    float a = x[i], b = y ? y[i] : 0.f, r = 0.f;
+    switch (op) {
+      case 0: r = fps::sin_(a); break;
+      case 1: r = fps::cos_(a); break;
+      case 2: r = fps::tan_(a); break;
+      case 3: r = fps::exp_(a); break;
+      case 4: r = fps::log_(a); break;
+      case 5: r = fps::acos_(a); break;
+      case 6: r = fps::asin_(a); break;
+      case 7: r = fps::atan_(a); break;
+      case 8: r = fps::pow_(a, b); break;
+      case 9: r = fps::rsqrt_(a); break;
+      case 10: r = fps::fmin_(a, b); break;
+      case 11: r = fps::fmax_(a, b); break;
+      case 12: r = (float)fps::f2i_(a); break;
+    }
+    out[i] = r;
+  }
+}
+
 uint32_t oracle_wang_hash(uint32_t v) { return WangHash(v); }
 void oracle_rng_floats(uint32_t seed, int n, float* out) {
   Rng r(seed);

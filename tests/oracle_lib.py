@@ -45,6 +45,7 @@ def lib():
         L.oracle_tonemap.argtypes = [fp, fp, C.c_int, C.c_int]
         L.oracle_primary_ids.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
         L.oracle_primary_ids_bruteforce.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
+        L.oracle_fps.argtypes = [C.c_int, fp, fp, C.c_int, fp]
         L.oracle_wang_hash.argtypes = [C.c_uint32]
         L.oracle_wang_hash.restype = C.c_uint32
         L.oracle_rng_floats.argtypes = [C.c_uint32, C.c_int, fp]
@@ -150,6 +151,18 @@ class Oracle:
         o = np.zeros(3, np.float32)
         ok = self.L.oracle_sample(self.h, pixel, it, _fp(o))
         return bool(ok), o
+
+
+FPS_OPS = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "asin": 6, "atan": 7, "pow": 8, "rsqrt": 9,
+           "fmin": 10, "fmax": 11, "f2i": 12}
+
+
+def fps(op, x, y=None):
+    x = _f32(x)
+    out = np.empty_like(x)
+    yy = _fp(_f32(y)) if y is not None else None
+    lib().oracle_fps(FPS_OPS[op], _fp(x), yy, x.size, _fp(out))
+    return out
 
 
 def wang_hash(v):

@@ -1,0 +1,124 @@
+"""The CPU oracle against the committed golden fixtures (tests/golden), the
+Thrust known answer, and a BVH-free brute force."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+VEC = json.load(open(os.path.join(GOLD, "vectors.json")))
+SCENES = sorted(VEC["scenes"])
+
+
+def scene_path(key):
+    return os.path.join(GOLD, "scenes", key, "scene.json")
+
+
+def test_minstd_known_answer():
+    # thrust/random/linear_congruential_engine.h: "the 10000th consecutive invocation of a
+    # default-constructed object of type minstd_rand shall produce the value 399268537"
+    assert int(ol.rng_raw(1, 10000)[-1]) == 399268537
+    assert VEC["rng"]["minstd_10000th_seed1"] == 399268537
+
+
+def test_rng_stream_and_hash():
+    for k, v in VEC["rng"]["wang_hash"].items():
+        assert ol.wang_hash(int(k)) == v
+    seed = VEC["rng"]["seed_pixel0_iter1"]
+    assert (ol.wang_hash(0) + ol.wang_hash(1)) & 0xffffffff == seed
+    assert [int(x) for x in ol.rng_raw(seed, 8)] == VEC["rng"]["first8_raw_pixel0_iter1"]
+    got = ol.rng_floats(seed, 8)
+    assert got.tolist() == VEC["rng"]["first8_floats_pixel0_iter1"]
+    # u = float(x - 1) / 2^31 stays inside [0, 1]
+    u = ol.rng_floats(12345, 100000)
+    assert u.min() >= 0.0 and u.max() <= 1.0
+
+
+@pytest.mark.parametrize("key", SCENES)
+def test_function_vectors(key):
+    sv = VEC["scenes"][key]
+    o = ol.Oracle(scene_path(key))
+    assert (o.n_prims, o.n_nodes, o.n_lights) == (sv["n_prims"], sv["n_nodes"], sv["n_lights"])
+    for c in sv["camera_rays"]:
+        assert o.camera_ray(c["x"], c["y"], c["iter"]).tolist() == c["ray"]
+    for t in sv["trace"]:
+        pid, h = o.trace(t["origin"], t["dir"], 1e-3)
+        assert pid == t["prim"]
+        if pid >= 0:
+            assert h.tolist() == t["hit"]
+        assert o.occluded(t["origin"], t["dir"], 1e-3, 5.0) == t["occluded_to_5"]
+    n, dpdu = [0.0, 1.0, 0.0], [1.0, 0.0, 0.0]
+    for b in sv["bsdf"]:
+        s = o.bsdf_sample(b["mat"], b["wo"], n, dpdu, [0.3, 0.6], b["u"])
+        np.testing.assert_array_equal(s, np.float32(b["sample"]))
+        e = o.bsdf_eval(b["mat"], b["wo"], s[:3], n, dpdu, [0.3, 0.6])
+        np.testing.assert_array_equal(e, np.float32(b["eval"]))
+    for l in sv["lights"]:
+        np.testing.assert_array_equal(o.light_sample(l["idx"], [0.1, 0.5, 0.2], [0.37, 0.58]), np.float32(l["sample"]))
+    for s in sv["samples"]:
+        ok, rgb = o.sample(s["pixel"], s["iter"])
+        assert ok == s["ok"]
+        np.testing.assert_array_equal(rgb, np.float32(s["rgb"]))
+
+
+@pytest.mark.parametrize("key", SCENES)
+def test_images_and_ids(key):
+    sv = VEC["scenes"][key]
+    o = ol.Oracle(scene_path(key))
+    c = ol.Counts()
+    acc = o.render(1, sv["spp"], 4, counts=c)
+    np.testing.assert_array_equal(acc, np.load(os.path.join(GOLD, key + "_sum.npy")))
+    np.testing.assert_array_equal(o.primary_ids(1), np.load(os.path.join(GOLD, key + "_ids.npy")))
+    assert c.as_dict() == sv["counts"]
+    # thread count and row splitting do not change a single bit
+    acc1 = o.render(1, sv["spp"], 1)
+    np.testing.assert_array_equal(acc, acc1)
+    half = o.height // 2
+    acc2 = o.render(1, sv["spp"], 2, rows=(0, half))
+    o.render(1, sv["spp"], 2, acc=acc2, rows=(half, o.height))
+    np.testing.assert_array_equal(acc, acc2)
+    # accumulation is in iteration order: two halves chained equal one run
+    acc3 = o.render(1, sv["spp"] // 2, 4)
+    o.render(1 + sv["spp"] // 2, sv["spp"] - sv["spp"] // 2, 4, acc=acc3)
+    np.testing.assert_array_equal(acc, acc3)
+
+
+@pytest.mark.parametrize("key", ["cornell_ao", "cornell_vpt", "stairs_pt"])
+def test_bvh_matches_bruteforce(key):
+    """Closest hits found through the BVH equal a linear scan over every primitive."""
+    o = ol.Oracle(scene_path(key))
+    for it in (1, 5):
+        np.testing.assert_array_equal(o.primary_ids(it), o.primary_ids(it, bruteforce=True))
+
+
+def test_ao_sample_values():
+    """On a triangle (orthonormal shading frame) an AO sample is 0 when occluded and
+    cos/pdf = pi when not; a miss is 1.  (Spheres carry the reference's non-orthogonal
+    tangent, sphere.h:81, so their values spread.)"""
+    o = ol.Oracle(scene_path("cornell_ao"))
+    ids = o.primary_ids(1)
+    seen = set()
+    for p in range(0, o.width * o.height, 11):
+        pid = ids.ravel()[p]
+        ok, rgb = o.sample(p, 1)
+        assert ok and rgb[0] == rgb[1] == rgb[2]
+        if pid < 0:
+            assert rgb[0] == 1.0
+        elif pid not in (0, 1) or True:
+            seen.add(round(float(rgb[0]), 3))
+    assert 0.0 in seen and 3.142 in seen
+
+
+def test_tonemap_matches_formula():
+    o = ol.Oracle(scene_path("cornell_pt"))
+    x = np.float32([[0.0, 0.004, 0.1], [1.0, 5.0, 100.0]])
+    f = o.tonemap(x, True)
+    c = np.maximum(x.astype(np.float64) - 0.004, 0)
+    ref = (c * (6.2 * c + 0.5)) / (c * (6.2 * c + 1.7) + 0.06)
+    np.testing.assert_allclose(f, ref, rtol=1e-5, atol=1e-7)
+    g = o.tonemap(x, False)
+    ref = np.power(np.maximum(x.astype(np.float64), 1e-5) * 1.41421356, 1 / 2.2)
+    np.testing.assert_allclose(g, ref, rtol=1e-5)
