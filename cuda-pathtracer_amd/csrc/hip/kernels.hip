@@ -448,10 +448,8 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 // A wavefront claims rays kChunk at a time from the queue's work counter and
 // keeps its 64 lanes fed: when kRefillIdle lanes have finished their rays the
 // idle lanes take the next unclaimed ones, so a long ray does not hold 63 idle
-// lanes hostage.  Between refills the lanes advance in two phases, all lanes
-// that stand at an inner node first (until none does), then all lanes that
-// stand at a leaf, so that node code and primitive code are not interleaved
-// lane by lane.
+// lanes hostage.  Between refills every step does the kind of work (a 4-wide
+// node, or one primitive test) that more lanes are waiting for.
 //   ANY=false: closest hit; (t, prim, b1, b2) goes into the queue entry.
 //   ANY=true:  any hit; an occluded ray clears the pending light-sampled term
 //              of its path.
@@ -526,18 +524,34 @@ __global__ __launch_bounds__(kWave) void k_trace(LaunchCtx L, RayQueue q, WalkAu
       if (!more) break;
       continue;
     }
-    // phase 1: inner nodes
-    while (__any(cur >= 0)) {
-      if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
-    }
-    // phase 2: leaves
-    if (cur != kRefEmpty) {
-      bool found = leaf_step<ANY>(S, ~cur, o, d, maxD, tmin, hit);
-      if (ANY && found) {
-        occluded = true;
-        cur = kRefEmpty;
-      } else {
-        cur = stack_next(st, lane, hit.t);
+    // Advance until enough lanes are free again.  Each step the wavefront does
+    // whichever kind of work more of its lanes are waiting for: one 4-wide node
+    // for every lane that stands at an inner node, or one primitive test for
+    // every lane that stands in a leaf (a leaf reference is ~index of the next
+    // primitive to test, so the cursor lives in `cur` itself).
+    for (;;) {
+      unsigned long long m_inner = __ballot(cur >= 0);
+      unsigned long long m_leaf = __ballot(cur < 0 && cur != kRefEmpty);
+      int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf);
+      int n_free = kWave - n_inner - n_leaf;
+      if (n_inner + n_leaf == 0) break;
+      if (more && n_free >= kRefillIdle) break;
+      if (n_inner >= n_leaf) {
+        if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
+      } else if (cur < 0 && cur != kRefEmpty) {
+        int i = ~cur;
+        float t, b1, b2;
+        bool last;
+        bool found = prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last);
+        if (found) {
+          if (ANY) {
+            occluded = true;
+          } else if (t < hit.t || i > hit.prim) {
+            hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2;
+          }
+        }
+        if (ANY && found) cur = kRefEmpty;
+        else cur = last ? stack_next(st, lane, hit.t) : ~(i + 1);
       }
     }
   }
