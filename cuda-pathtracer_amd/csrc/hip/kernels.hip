@@ -20,10 +20,28 @@
 namespace caster {
 
 constexpr int kWave = 64;
-constexpr int kLdsDepth = 16;     // traversal-stack entries per lane kept in LDS
-constexpr int kSpillDepth = 48;   // further entries in a per-lane column in HBM
-constexpr uint32_t kChunk = 256;  // rays a wavefront claims from a queue per atomic
-constexpr int kRefillIdle = 16;   // refill a wavefront once this many lanes are idle
+#ifndef CASTER_LDS_DEPTH
+#define CASTER_LDS_DEPTH 16
+#endif
+#ifndef CASTER_REFILL
+#define CASTER_REFILL 24
+#endif
+#ifndef CASTER_CHUNK
+#define CASTER_CHUNK 64
+#endif
+#ifndef CASTER_SHARDS
+#define CASTER_SHARDS 8
+#endif
+#ifndef CASTER_VOTE_NUM  // do node work when n_inner * NUM >= n_leaf * DEN
+#define CASTER_VOTE_NUM 1
+#define CASTER_VOTE_DEN 1
+#endif
+constexpr int kLdsDepth = CASTER_LDS_DEPTH;  // traversal-stack entries per lane kept in LDS
+constexpr int kSpillDepth = 48;              // further entries in a per-lane column in HBM
+constexpr uint32_t kChunk = CASTER_CHUNK;        // rays a wavefront claims from a queue per atomic
+constexpr uint32_t kWorkShards = CASTER_SHARDS;  // work counters per queue
+constexpr uint32_t kWorkPad = 64;                 // counters sit 256 bytes apart: one memory channel each
+constexpr int kRefillIdle = CASTER_REFILL;   // refill a wavefront once this many lanes are idle
 
 // ------------------------------------------------------------------ vectors
 struct V3 { float x, y, z; };
@@ -291,7 +309,7 @@ __device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, float max
 // a per-lane column in HBM (lane-strided too, so a wavefront's spill is one
 // coalesced store).
 struct WalkAux {
-  uint32_t* work;         // next unclaimed ray of the queue being traced
+  uint32_t* work;         // kWorkShards counters: next unclaimed ray of each part of the queue being traced
   uint2* spill;           // kSpillDepth x spill_stride entries
   uint32_t spill_stride;  // lanes in the launch grid
 };
@@ -445,7 +463,7 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 
 // Traces every ray of a queue with persistent wavefronts.
 //
-// A wavefront claims rays kChunk at a time from the queue's work counter and
+// A wavefront claims rays a chunk at a time from the queue's work counter and
 // keeps its 64 lanes fed: when kRefillIdle lanes have finished their rays the
 // idle lanes take the next unclaimed ones, so a long ray does not hold 63 idle
 // lanes hostage.  Between refills every step does the kind of work (a 4-wide
@@ -468,7 +486,17 @@ __global__ __launch_bounds__(kWave) void k_trace(LaunchCtx L, RayQueue q, WalkAu
   Hit hit;
   hit.t = 0.f; hit.prim = -1; hit.b1 = hit.b2 = 0.f;
   bool occluded = false;
-  uint32_t chunk_next = 0, chunk_end = 0;
+  // this wavefront's first chunk is assigned statically (no atomic storm at
+  // launch): the work counters start at the end of the static assignment
+  const uint32_t part = ((count + kWorkShards - 1) / kWorkShards + kWave - 1) / kWave * kWave;
+  uint32_t shard = blockIdx.x % kWorkShards, shards_tried = 0;
+  uint32_t chunk_next, chunk_end;
+  {
+    uint32_t lo = shard * part, hi = lo + part < count ? lo + part : count;
+    uint32_t base = (blockIdx.x / kWorkShards) * kChunk;
+    chunk_next = lo + base < hi ? lo + base : 0;
+    chunk_end = lo + base < hi ? (chunk_next + kChunk < hi ? chunk_next + kChunk : hi) : 0;
+  }
   bool more = true;
   for (;;) {
     // retire finished rays
@@ -490,15 +518,25 @@ __global__ __launch_bounds__(kWave) void k_trace(LaunchCtx L, RayQueue q, WalkAu
     uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     if (more && n_idle >= (uint32_t)kRefillIdle) {
       if (chunk_next == chunk_end) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(aux.work, kChunk);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= count) {
-          more = false;
-        } else {
-          chunk_next = base;
-          chunk_end = base + kChunk < count ? base + kChunk : count;
+        // Claim the next chunk.  The queue is cut into kWorkShards contiguous
+        // parts with a work counter each: same-address atomics with a return
+        // value retire at only ~15 per microsecond on this chip, so one shared
+        // counter would bound the kernel.  A wavefront works on "its" part
+        // first and moves on to the next part when that one is exhausted.
+        while (shards_tried < kWorkShards) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(aux.work + shard * kWorkPad, kChunk);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          uint32_t lo = shard * part, hi = lo + part < count ? lo + part : count;
+          if (lo + base < hi) {
+            chunk_next = lo + base;
+            chunk_end = chunk_next + kChunk < hi ? chunk_next + kChunk : hi;
+            break;
+          }
+          shard = shard + 1 == kWorkShards ? 0 : shard + 1;
+          ++shards_tried;
         }
+        if (shards_tried == kWorkShards) more = false;
       }
       if (more) {
         uint32_t avail = chunk_end - chunk_next;
@@ -536,7 +574,7 @@ __global__ __launch_bounds__(kWave) void k_trace(LaunchCtx L, RayQueue q, WalkAu
       int n_free = kWave - n_inner - n_leaf;
       if (n_inner + n_leaf == 0) break;
       if (more && n_free >= kRefillIdle) break;
-      if (n_inner >= n_leaf) {
+      if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
         if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
       } else if (cur < 0 && cur != kRefEmpty) {
         int i = ~cur;
@@ -1699,8 +1737,10 @@ __global__ void k_gather_ids(LaunchCtx L, RayQueue q, int32_t* ids) {
 // Adds the three queue lengths of a finished bounce to the ray statistics and
 // clears the queues that the next shade pass appends to.
 __global__ void k_roll(Stats* st, const uint32_t* n_ext, const uint32_t* n_shadow, const uint32_t* n_probe,
-                       uint32_t* clear0, uint32_t* clear1, uint32_t* clear2, uint32_t ext_override, uint32_t* work3) {
-  if (work3) { work3[0] = 0; work3[1] = 0; work3[2] = 0; }
+                       uint32_t* clear0, uint32_t* clear1, uint32_t* clear2, uint32_t ext_override, uint32_t* work,
+                       uint32_t n_work, uint32_t work_init) {
+  // work counters start past the statically assigned first chunk of every wavefront
+  for (uint32_t i = 0; i < n_work; ++i) work[i * kWorkPad] = work_init;
   if (ext_override) st->rays[0] += ext_override;
   else if (n_ext) st->rays[0] += *n_ext;
   if (n_shadow) st->rays[1] += *n_shadow;

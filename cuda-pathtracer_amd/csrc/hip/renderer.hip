@@ -222,7 +222,8 @@ struct caster_renderer {
   DevScene S{};
   PathState P{};
   RayQueue ext[2]{}, shadow{}, probe{};
-  uint32_t* counters = nullptr;  // queue lengths: ext0, ext1, shadow, probe; work counters: 4, 5, 6
+  uint32_t* counters = nullptr;  // queue lengths: ext0, ext1, shadow, probe; then 3 x kWorkShards work counters
+  uint32_t work_init = 0;
   WalkAux aux{};
   int walk_grid = 0;
   StageArea stage{};
@@ -339,8 +340,8 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
   if ((rc = dev_alloc(r, &r->P.pend_x, n))) return rc;
   if ((rc = dev_alloc(r, &r->P.pend_y, n))) return rc;
   if ((rc = dev_alloc(r, &r->P.beta_prev, n))) return rc;
-  if ((rc = dev_alloc(r, &r->counters, 8))) return rc;
-  HIPCHECK(hipMemset(r->counters, 0, 8 * sizeof(uint32_t)));
+  if ((rc = dev_alloc(r, &r->counters, 64 + 3 * kWorkShards * kWorkPad))) return rc;
+  HIPCHECK(hipMemset(r->counters, 0, (64 + 3 * kWorkShards * kWorkPad) * sizeof(uint32_t)));
   if ((rc = alloc_queue(r, r->ext[0], n, true, r->counters + 0))) return rc;
   if ((rc = alloc_queue(r, r->ext[1], n, true, r->counters + 1))) return rc;
   if ((rc = alloc_queue(r, r->shadow, n, false, r->counters + 2))) return rc;
@@ -363,10 +364,11 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
     if ((rc = alloc_queue(r, r->stage.probe, cap, false, nullptr))) return rc;
   }
   // persistent traversal grid: 8 KB of LDS stack per wavefront -> 20 wavefronts per CU
-  r->walk_grid = r->n_cu * 20;
+  r->walk_grid = r->n_cu * (kLdsDepth <= 12 ? 24 : (kLdsDepth <= 16 ? 20 : 12));
   r->aux.spill_stride = (uint32_t)r->walk_grid * kWave;
   if ((rc = dev_alloc(r, &r->aux.spill, (size_t)r->aux.spill_stride * kSpillDepth))) return rc;
-  r->aux.work = r->counters + 4;
+  r->aux.work = r->counters + 64;
+  r->work_init = ((uint32_t)r->walk_grid + kWorkShards - 1) / kWorkShards * kChunk;
   if ((rc = dev_alloc(r, &r->stats, 1))) return rc;
   HIPCHECK(hipMemset(r->stats, 0, sizeof(Stats)));
   size_t npix = (size_t)sc.width * sc.height;
@@ -412,7 +414,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   LaunchCtx L = ctx_of(r);
   const uint32_t total = (uint32_t)S.slots_per_iter * n;
   const int walk_grid = r->walk_grid;
-  auto aux_for = [&](int which) { WalkAux a = r->aux; a.work = r->counters + 4 + which; return a; };
+  auto aux_for = [&](int which) { WalkAux a = r->aux; a.work = r->counters + 64 + which * kWorkShards * kWorkPad; return a; };
   const int shade_grid = r->shade_grid;
   const int gen_grid = (int)std::min<uint32_t>((total + kWave - 1) / kWave, (uint32_t)r->n_cu * 32);
   int cur = 0;
@@ -422,7 +424,8 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   }
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, r->ext[0].count, total);
   hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                     (const uint32_t*)nullptr, r->ext[1].count, r->shadow.count, r->probe.count, 0u, r->counters + 4);
+                     (const uint32_t*)nullptr, r->ext[1].count, r->shadow.count, r->probe.count, 0u, r->counters + 64,
+                     3u * kWorkShards, r->work_init);
   const uint32_t live_rays = (uint32_t)S.width * (uint32_t)(r->y1 - r->y0) * n;
   auto bounce = [&](int b) {
     RayQueue& q = r->ext[cur];
@@ -452,7 +455,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
     // the camera queue also holds slots outside the image / row range: count only live rays
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)q.count,
                        (const uint32_t*)r->shadow.count, (const uint32_t*)r->probe.count, q.count, r->shadow.count,
-                       r->probe.count, b == 0 ? live_rays : 0u, r->counters + 4);
+                       r->probe.count, b == 0 ? live_rays : 0u, r->counters + 64, 3u * kWorkShards, r->work_init);
     cur ^= 1;
   };
   if (S.integrator == IT_AO) {
@@ -640,13 +643,14 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, r->stream, L, r->ext[0], iter, 1u,
                      0, r->S.height);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->ext[0].count, total);
-  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->counters + 4, 0u);
-  {
-    WalkAux a = r->aux;
-    a.work = r->counters + 4;
-    hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid), dim3(kWave), 0, r->stream, L, r->ext[0], a);
-  }
-  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->counters + 4, 0u);
+  auto reset_work = [&]() {
+    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, r->stream, r->stats, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, 0u, r->counters + 64, 3u * kWorkShards, r->work_init);
+  };
+  reset_work();
+  hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid), dim3(kWave), 0, r->stream, L, r->ext[0], r->aux);
+  reset_work();
   hipLaunchKernelGGL(k_gather_ids, dim3(r->n_cu * 4), dim3(256), 0, r->stream, L, r->ext[0], r->ids);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->ext[0].count, 0u);
   HIPCHECK(hipGetLastError());

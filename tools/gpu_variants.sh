@@ -1,0 +1,13 @@
+# benchmark every build under cuda-pathtracer_amd/variants/ plus the default one
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+: > gpurun_out/variants.txt
+for lib in cuda-pathtracer_amd/libcaster.so cuda-pathtracer_amd/variants/*.so cuda-pathtracer_amd/libcaster.so; do
+  CASTER_LIB=$PWD/$lib timeout -k 10 200 python -u bench.py --steps 6 --warmup 2 --no-cpu > gpurun_out/v.json 2> gpurun_out/v.err || { echo "$lib FAILED"; tail -3 gpurun_out/v.err; continue; }
+  python - "$lib" <<'PY' | tee -a gpurun_out/variants.txt
+import json, sys
+d = json.load(open('gpurun_out/v.json'))
+k = d['kernel_ms']
+print('%-45s %7.1f Msamples/s  ext %.1f shade %.1f shadow %.1f probe %.1f' % (sys.argv[1][-45:], d['value'], k['extend'], k['shade'], k['shadow'], k['probe']))
+PY
+done
