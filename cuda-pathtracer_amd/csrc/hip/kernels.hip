@@ -21,7 +21,7 @@ namespace caster {
 
 constexpr int kWave = 64;
 #ifndef CASTER_LDS_DEPTH
-#define CASTER_LDS_DEPTH 16
+#define CASTER_LDS_DEPTH 12
 #endif
 #ifndef CASTER_REFILL
 #define CASTER_REFILL 24
@@ -471,8 +471,11 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 //   ANY=false: closest hit; (t, prim, b1, b2) goes into the queue entry.
 //   ANY=true:  any hit; an occluded ray clears the pending light-sampled term
 //              of its path.
+#ifndef CASTER_TRACE_WAVES
+#define CASTER_TRACE_WAVES 5
+#endif
 template <bool ANY>
-__global__ __launch_bounds__(kWave) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
+__global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
   const DevScene& S = L.S;
   const uint32_t lane = threadIdx.x;
@@ -1160,7 +1163,10 @@ __device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li) {
 
 // One vertex of Path() (pathtracer.cu:897-1007) for every path whose
 // extension ray has been traced.
-__global__ __launch_bounds__(kWave) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
+#ifndef CASTER_SHADE_WAVES
+#define CASTER_SHADE_WAVES 4
+#endif
+__global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
   const DevScene& S = L.S;
   const PathState& P = L.P;
   const uint32_t count = *cur.count;

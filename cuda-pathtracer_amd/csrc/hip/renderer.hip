@@ -364,7 +364,11 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
     if ((rc = alloc_queue(r, r->stage.probe, cap, false, nullptr))) return rc;
   }
   // persistent traversal grid: 8 KB of LDS stack per wavefront -> 20 wavefronts per CU
-  r->walk_grid = r->n_cu * (kLdsDepth <= 12 ? 24 : (kLdsDepth <= 16 ? 20 : 12));
+  {
+    int by_lds = (160 * 1024) / (kLdsDepth * kWave * 8);
+    int by_regs = CASTER_TRACE_WAVES * 4;
+    r->walk_grid = r->n_cu * std::min(by_lds, by_regs);
+  }
   r->aux.spill_stride = (uint32_t)r->walk_grid * kWave;
   if ((rc = dev_alloc(r, &r->aux.spill, (size_t)r->aux.spill_stride * kSpillDepth))) return rc;
   r->aux.work = r->counters + 64;
