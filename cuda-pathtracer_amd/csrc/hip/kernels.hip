@@ -471,6 +471,9 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 //   ANY=false: closest hit; (t, prim, b1, b2) goes into the queue entry.
 //   ANY=true:  any hit; an occluded ray clears the pending light-sampled term
 //              of its path.
+#ifndef CASTER_SPECULATE
+#define CASTER_SPECULATE 1
+#endif
 #ifndef CASTER_TRACE_WAVES
 #define CASTER_TRACE_WAVES 5
 #endif
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
   Stack st{s_stack, aux.spill + (blockIdx.x * kWave + lane), aux.spill_stride, 0};
   int idx = -1;
   int cur = kRefEmpty;
+  int pend = kRefEmpty;  // a leaf waiting for its primitives to be tested
   V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 1);
   float tmin = 0.f, maxD = 1.f;
   Hit hit;
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
   bool more = true;
   for (;;) {
     // retire finished rays
-    if (idx >= 0 && cur == kRefEmpty) {
+    if (idx >= 0 && cur == kRefEmpty && pend == kRefEmpty) {
       if (ANY) {
         if (occluded) {
           int slot = q.slot[idx];
@@ -566,11 +570,48 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
       continue;
     }
     // Advance until enough lanes are free again.  Each step the wavefront does
-    // whichever kind of work more of its lanes are waiting for: one 4-wide node
-    // for every lane that stands at an inner node, or one primitive test for
-    // every lane that stands in a leaf (a leaf reference is ~index of the next
-    // primitive to test, so the cursor lives in `cur` itself).
+    // whichever kind of work more of its lanes can do: one 4-wide node for every
+    // lane that stands at an inner node, or one primitive test for every lane
+    // that holds a leaf.  A lane that reaches a leaf parks it in `pend` (a leaf
+    // reference is ~index of the next primitive to test, so the cursor lives in
+    // the reference itself) and goes on with the next deferred node, so that it
+    // keeps taking part in node steps; the parked leaf may later shorten the ray
+    // and make some of that node work unnecessary, never wrong.
     for (;;) {
+#if CASTER_SPECULATE
+      if (cur < 0 && cur != kRefEmpty && pend == kRefEmpty) {
+        pend = cur;
+        cur = stack_next(st, lane, hit.t);
+      }
+      unsigned long long m_inner = __ballot(cur >= 0);
+      unsigned long long m_leaf = __ballot(pend != kRefEmpty);
+      unsigned long long m_busy = __ballot(cur != kRefEmpty || pend != kRefEmpty);
+      int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf);
+      int n_free = kWave - __popcll(m_busy);
+      if (m_busy == 0) break;
+      if (more && n_free >= kRefillIdle) break;
+      if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
+        if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
+      } else if (pend != kRefEmpty) {
+        int i = ~pend;
+        float t, b1, b2;
+        bool last;
+        bool found = prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last);
+        if (found) {
+          if (ANY) {
+            occluded = true;
+          } else if (t < hit.t || i > hit.prim) {
+            hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2;
+          }
+        }
+        if (ANY && found) {
+          cur = kRefEmpty;
+          pend = kRefEmpty;
+        } else {
+          pend = last ? kRefEmpty : ~(i + 1);
+        }
+      }
+#else
       unsigned long long m_inner = __ballot(cur >= 0);
       unsigned long long m_leaf = __ballot(cur < 0 && cur != kRefEmpty);
       int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf);
@@ -594,6 +635,7 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
         if (ANY && found) cur = kRefEmpty;
         else cur = last ? stack_next(st, lane, hit.t) : ~(i + 1);
       }
+#endif
     }
   }
 }
@@ -1236,7 +1278,10 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
               eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
               float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
               x = weight * fr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
-              want_shadow = true;
+              // The reference traces the shadow ray before it evaluates the BSDF
+              // (pathtracer.cu:933-940); when the term is exactly zero (light behind
+              // the surface, zero BSDF) visibility cannot change Ld, so no ray is sent.
+              want_shadow = !is_black(x);
               so = pos; sd = ldir; stmax = ltmax;
             }
             // BSDF sampling for direct light

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 : > gpurun_out/variants.txt
-for lib in cuda-pathtracer_amd/libcaster.so cuda-pathtracer_amd/variants/*.so cuda-pathtracer_amd/libcaster.so; do
+for lib in cuda-pathtracer_amd/libcaster.so $(ls cuda-pathtracer_amd/variants/*.so 2>/dev/null) cuda-pathtracer_amd/libcaster.so; do
   CASTER_LIB=$PWD/$lib timeout -k 10 200 python -u bench.py --steps 6 --warmup 2 --no-cpu > gpurun_out/v.json 2> gpurun_out/v.err || { echo "$lib FAILED"; tail -3 gpurun_out/v.err; continue; }
   python - "$lib" <<'PY' | tee -a gpurun_out/variants.txt
 import json, sys
