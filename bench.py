@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (roofline then uses no counts)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--shard", choices=["spp", "tile"], default="spp")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (gloo + --share-gpu rehearses N>1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses device 0 (rehearsal only)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,10 +82,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    dev_index = 0 if a.share_gpu else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(a.backend)
+    coll_dev = "cuda:%d" % dev_index if a.backend == "nccl" else "cpu"
 
     def barrier():
         if dist is not None:
@@ -92,12 +100,21 @@ def main():
     path = scene_path(a.scene, a.detail, a.width, a.height, a.depth, rank, barrier)
     scene = caster.Scene(path)
     spp = a.spp_per_step
-    r = caster.Renderer(scene, local_rank, spp)
+    sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
+    r = caster.Renderer(scene, dev_index, spp)
     npix = scene.width * scene.height
+    rows = (0, scene.height)
+    if world > 1 and a.shard == "tile":
+        rows = sharding.row_band(scene.height, rank, world)
+        r.set_rows(*rows)
 
-    film = torch.empty(npix * 3, dtype=torch.float32, device="cuda:%d" % local_rank) if world > 1 else None
+    film = torch.empty(npix * 3, dtype=torch.float32, device="cuda:%d" % dev_index) if world > 1 else None
 
     def first_iter(step):
+        # spp: block `step * world + rank` of the iteration sequence (sharding.spp_blocks with
+        # block = spp); tile: every rank renders the same iterations for its own rows
+        if a.shard == "tile":
+            return 1 + step * spp
         return 1 + (step * world + rank) * spp
 
     step_no = 0
@@ -117,12 +134,16 @@ def main():
         step_no += 1
     if world > 1:
         r.read_film_device(film.data_ptr(), 2)
-        dist.reduce(film, 0)
+        if coll_dev == "cpu":
+            host_film = film.cpu()
+            sharding.reduce_film(host_film, dist, 0)
+        else:
+            sharding.reduce_film(film, dist, 0)
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -130,7 +151,7 @@ def main():
     kt = r.kernel_times()
     rays = torch.tensor(st["rays"] + [st["samples"], st["invalid"], st["stack_overflow"]], dtype=torch.float64)
     if world > 1:
-        rays = rays.to("cuda:%d" % local_rank)
+        rays = rays.to(coll_dev)
         dist.all_reduce(rays)
         rays = rays.cpu()
     rays = [float(x) for x in rays]
@@ -147,7 +168,7 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if a.shard == "spp" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -160,7 +181,9 @@ def main():
                     a.scene, scene.info.n_prims, scene.info.n_nodes, scene.width, scene.height,
                     caster.INTEGRATOR_NAMES[scene.integrator], scene.info.max_depth),
                 "spp_per_step": spp,
-                "sharding": "spp (disjoint iterations per rank, one film reduce)" if world > 1 else "none",
+                "sharding": ("none" if world == 1 else
+                             "spp (disjoint iterations per rank, one film reduce)" if a.shard == "spp" else
+                             "tile (bands of scanlines per rank, one film reduce)"),
             },
             "kernel_ms": {k: v[0] for k, v in kt.items()},
             "kernel_launches": {k: v[1] for k, v in kt.items()},
