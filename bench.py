@@ -69,7 +69,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--iters-in-flight", type=int, default=0, help="iterations per batch of paths (0: library default)")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams batches are dealt to (0: library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (roofline then uses no counts)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--shard", choices=["spp", "tile"], default="spp")
@@ -101,7 +103,7 @@ def main():
     scene = caster.Scene(path)
     spp = a.spp_per_step
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
-    r = caster.Renderer(scene, dev_index, spp)
+    r = caster.Renderer(scene, dev_index, a.iters_in_flight, a.streams)
     npix = scene.width * scene.height
     rows = (0, scene.height)
     if world > 1 and a.shard == "tile":

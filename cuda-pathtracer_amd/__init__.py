@@ -57,7 +57,8 @@ _lib = None
 
 # every symbol include/caster.h declares
 EXPORTS = [
-    "caster_scene_load", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_set_rows",
+    "caster_scene_load", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams",
+    "caster_set_rows",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
     "caster_film_add_device", "caster_primary_ids", "caster_get_stats", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
@@ -99,6 +100,7 @@ def lib():
         L.caster_scene_free.restype = None
         L.caster_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
         L.caster_begin.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.caster_begin_streams.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.caster_set_rows.argtypes = [vp, C.c_int, C.c_int]
         L.caster_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
         L.caster_render_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
@@ -154,9 +156,9 @@ class Scene:
 class Renderer:
     """Device-side render state for one scene on one GPU."""
 
-    def __init__(self, scene, device=0, iters_in_flight=0):
+    def __init__(self, scene, device=0, iters_in_flight=0, n_streams=0):
         h = C.c_void_p()
-        _check(lib().caster_begin(scene._h, int(device), int(iters_in_flight), C.byref(h)))
+        _check(lib().caster_begin_streams(scene._h, int(device), int(iters_in_flight), int(n_streams), C.byref(h)))
         self._h = h
         self.width, self.height = scene.width, scene.height
         self.integrator = scene.integrator

@@ -4,9 +4,10 @@
 // (CUDA-PathTracer/tracer/pathtracer.cu:2554-2742): instead of one megakernel
 // launch, one Output launch, a device synchronisation and a frame download per
 // sample, a call traces `iters_in_flight` samples per pixel as one batch of
-// paths through generate -> [extend -> shade -> shadow/probe]* -> finish on a
-// single HIP stream with no host round trip inside the batch (queue lengths
-// stay on the device), and the film stays resident until it is asked for.
+// paths through generate -> [extend -> shade -> shadow/probe]* -> finish on
+// one of a few HIP streams with no host round trip inside the batch (queue
+// lengths stay on the device), consecutive batches overlap on different
+// streams, and the film stays resident until it is asked for.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -202,6 +203,9 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
   }
 }
 
+constexpr int kDefaultStreams = 2;
+constexpr int kMaxStreams = 8;
+
 static float gamma_n(int n) {  // common.h:111-114: double arithmetic, float result
   const double me = (double)1.192092896e-07F * 0.5;
   return (float)((n * me) / (1 - n * me));
@@ -215,20 +219,31 @@ struct caster_scene {
   Scene scene;
 };
 
-struct caster_renderer {
-  int device = 0;
+// One render stream with everything a batch of paths in flight needs.  Batches
+// are dealt to the streams in turn, so the tail of one batch's kernels (few rays
+// left in the late bounces, single-thread bookkeeping launches) overlaps the
+// other stream's work; the scene arrays and the film are shared.
+struct Lane {
   hipStream_t stream = nullptr;
-  std::vector<void*> allocs;
-  DevScene S{};
   PathState P{};
   RayQueue ext[2]{}, shadow{}, probe{};
   uint32_t* counters = nullptr;  // queue lengths: ext0, ext1, shadow, probe; then 3 x kWorkShards work counters
-  uint32_t work_init = 0;
   WalkAux aux{};
-  int walk_grid = 0;
   StageArea stage{};
-  int shade_grid = 0;
   Stats* stats = nullptr;
+  hipEvent_t finish_done = nullptr;  // recorded after the lane's latest k_finish
+};
+
+struct caster_renderer {
+  int device = 0;
+  std::vector<Lane> lanes;
+  uint32_t next_lane = 0;
+  hipEvent_t last_finish = nullptr;  // the film is accumulated in iteration order: each k_finish waits for the one before
+  std::vector<void*> allocs;
+  DevScene S{};
+  uint32_t work_init = 0;
+  int walk_grid = 0;
+  int shade_grid = 0;
   float* acc = nullptr;
   float* film_tmp = nullptr;
   int32_t* ids = nullptr;
@@ -238,7 +253,7 @@ struct caster_renderer {
   uint64_t samples = 0;
   int y0 = 0, y1 = 0;
   int n_cu = 256;
-  // optional per-kernel-class timing with HIP events on the render stream
+  // optional per-kernel-class timing with HIP events on the render streams
   bool profiling = false;
   struct Timed { int cls; hipEvent_t a, b; };
   std::vector<Timed> pending_events;
@@ -279,13 +294,44 @@ static int alloc_queue(caster_renderer* r, RayQueue& q, uint32_t n, bool with_hi
   return CASTER_OK;
 }
 
-static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caster_renderer* r) {
+static int alloc_lane(caster_renderer* r, Lane& ln) {
+  int rc;
+  const uint32_t n = r->pool_slots;
+  HIPCHECK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+  HIPCHECK(hipEventCreateWithFlags(&ln.finish_done, hipEventDisableTiming));
+  if ((rc = dev_alloc(r, &ln.P.beta_rng, n))) return rc;
+  if ((rc = dev_alloc(r, &ln.P.li_flags, n))) return rc;
+  if ((rc = dev_alloc(r, &ln.P.pend_x, n))) return rc;
+  if ((rc = dev_alloc(r, &ln.P.pend_y, n))) return rc;
+  if ((rc = dev_alloc(r, &ln.P.beta_prev, n))) return rc;
+  if ((rc = dev_alloc(r, &ln.counters, 64 + 3 * kWorkShards * kWorkPad))) return rc;
+  HIPCHECK(hipMemset(ln.counters, 0, (64 + 3 * kWorkShards * kWorkPad) * sizeof(uint32_t)));
+  if ((rc = alloc_queue(r, ln.ext[0], n, true, ln.counters + 0))) return rc;
+  if ((rc = alloc_queue(r, ln.ext[1], n, true, ln.counters + 1))) return rc;
+  if ((rc = alloc_queue(r, ln.shadow, n, false, ln.counters + 2))) return rc;
+  if ((rc = alloc_queue(r, ln.probe, n, true, ln.counters + 3))) return rc;
+  // every shade wavefront owns a staging region large enough for all paths it can be given
+  uint32_t rounds = (n + kWave - 1) / kWave;
+  uint32_t per = (rounds + (uint32_t)r->shade_grid - 1) / (uint32_t)r->shade_grid;
+  ln.stage.region_cap = per * kWave;
+  uint32_t cap = ln.stage.region_cap * (uint32_t)r->shade_grid;
+  if ((rc = alloc_queue(r, ln.stage.next, cap, false, nullptr))) return rc;
+  if ((rc = alloc_queue(r, ln.stage.shadow, cap, false, nullptr))) return rc;
+  if ((rc = alloc_queue(r, ln.stage.probe, cap, false, nullptr))) return rc;
+  ln.aux.spill_stride = (uint32_t)r->walk_grid * kWave;
+  if ((rc = dev_alloc(r, &ln.aux.spill, (size_t)ln.aux.spill_stride * kSpillDepth))) return rc;
+  ln.aux.work = ln.counters + 64;
+  if ((rc = dev_alloc(r, &ln.stats, 1))) return rc;
+  HIPCHECK(hipMemset(ln.stats, 0, sizeof(Stats)));
+  return CASTER_OK;
+}
+
+static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n_streams, caster_renderer* r) {
   r->device = device_id;
   HIPCHECK(hipSetDevice(device_id));
   hipDeviceProp_t prop;
   HIPCHECK(hipGetDeviceProperties(&prop, device_id));
   r->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIPCHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
 
   HostArrays A;
   build_arrays(sc, A);
@@ -329,25 +375,16 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
   r->y0 = 0; r->y1 = sc.height;
 
   if (iters_in_flight <= 0) {
-    long long target = 16ll << 20;
+    // late bounces keep few rays alive: a batch needs tens of millions of paths
+    // for their launches to fill the chip
+    long long target = 32ll << 20;
     iters_in_flight = (int)std::max<long long>(1, std::min<long long>(64, target / S.slots_per_iter));
   }
+  if (n_streams <= 0) n_streams = kDefaultStreams;
+  if (n_streams > kMaxStreams) n_streams = kMaxStreams;
   r->iters_in_flight = iters_in_flight;
   r->pool_slots = (uint32_t)S.slots_per_iter * (uint32_t)iters_in_flight;
-  const uint32_t n = r->pool_slots;
-  if ((rc = dev_alloc(r, &r->P.beta_rng, n))) return rc;
-  if ((rc = dev_alloc(r, &r->P.li_flags, n))) return rc;
-  if ((rc = dev_alloc(r, &r->P.pend_x, n))) return rc;
-  if ((rc = dev_alloc(r, &r->P.pend_y, n))) return rc;
-  if ((rc = dev_alloc(r, &r->P.beta_prev, n))) return rc;
-  if ((rc = dev_alloc(r, &r->counters, 64 + 3 * kWorkShards * kWorkPad))) return rc;
-  HIPCHECK(hipMemset(r->counters, 0, (64 + 3 * kWorkShards * kWorkPad) * sizeof(uint32_t)));
-  if ((rc = alloc_queue(r, r->ext[0], n, true, r->counters + 0))) return rc;
-  if ((rc = alloc_queue(r, r->ext[1], n, true, r->counters + 1))) return rc;
-  if ((rc = alloc_queue(r, r->shadow, n, false, r->counters + 2))) return rc;
-  if ((rc = alloc_queue(r, r->probe, n, true, r->counters + 3))) return rc;
-  // shade grid: one wavefront per block, as many as are resident at once; every
-  // wavefront owns a staging region large enough for all paths it can be given
+  // shade grid: one wavefront per block, as many as are resident at once
   {
     int per_cu = 8;
     const void* fn = sc.integrator == IT_AO ? (const void*)k_shade_ao
@@ -355,26 +392,17 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 8;
     if (per_cu > 20) per_cu = 20;  // the vpt shade stage indexes the spill area sized for 20 wavefronts per CU
     r->shade_grid = r->n_cu * per_cu;
-    uint32_t rounds = (n + kWave - 1) / kWave;
-    uint32_t per = (rounds + (uint32_t)r->shade_grid - 1) / (uint32_t)r->shade_grid;
-    r->stage.region_cap = per * kWave;
-    uint32_t cap = r->stage.region_cap * (uint32_t)r->shade_grid;
-    if ((rc = alloc_queue(r, r->stage.next, cap, false, nullptr))) return rc;
-    if ((rc = alloc_queue(r, r->stage.shadow, cap, false, nullptr))) return rc;
-    if ((rc = alloc_queue(r, r->stage.probe, cap, false, nullptr))) return rc;
   }
-  // persistent traversal grid: 8 KB of LDS stack per wavefront -> 20 wavefronts per CU
+  // persistent traversal grid: as many wavefronts as LDS stacks and registers allow per CU
   {
     int by_lds = (160 * 1024) / (kLdsDepth * kWave * 8);
     int by_regs = CASTER_TRACE_WAVES * 4;
     r->walk_grid = r->n_cu * std::min(by_lds, by_regs);
   }
-  r->aux.spill_stride = (uint32_t)r->walk_grid * kWave;
-  if ((rc = dev_alloc(r, &r->aux.spill, (size_t)r->aux.spill_stride * kSpillDepth))) return rc;
-  r->aux.work = r->counters + 64;
   r->work_init = ((uint32_t)r->walk_grid + kWorkShards - 1) / kWorkShards * kChunk;
-  if ((rc = dev_alloc(r, &r->stats, 1))) return rc;
-  HIPCHECK(hipMemset(r->stats, 0, sizeof(Stats)));
+  r->lanes.resize((size_t)n_streams);
+  for (Lane& ln : r->lanes)
+    if ((rc = alloc_lane(r, ln))) return rc;
   size_t npix = (size_t)sc.width * sc.height;
   if ((rc = dev_alloc(r, &r->acc, npix * 3))) return rc;
   HIPCHECK(hipMemset(r->acc, 0, npix * 3 * sizeof(float)));
@@ -383,7 +411,12 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, caste
   return CASTER_OK;
 }
 
-static inline LaunchCtx ctx_of(caster_renderer* r) { return LaunchCtx{r->S, r->P, r->stats}; }
+static inline LaunchCtx ctx_of(caster_renderer* r, const Lane& ln) { return LaunchCtx{r->S, ln.P, ln.stats}; }
+
+static int sync_lanes(caster_renderer* r) {
+  for (Lane& ln : r->lanes) HIPCHECK(hipStreamSynchronize(ln.stream));
+  return CASTER_OK;
+}
 
 static hipEvent_t take_event(caster_renderer* r) {
   if (!r->free_events.empty()) { hipEvent_t e = r->free_events.back(); r->free_events.pop_back(); return e; }
@@ -393,12 +426,12 @@ static hipEvent_t take_event(caster_renderer* r) {
 }
 // Brackets one kernel launch with events when profiling is on.
 struct ScopedTimer {
-  caster_renderer* r; int cls; hipEvent_t a = nullptr, b = nullptr;
-  ScopedTimer(caster_renderer* r_, int cls_) : r(r_), cls(cls_) {
-    if (r->profiling) { a = take_event(r); b = take_event(r); (void)hipEventRecord(a, r->stream); }
+  caster_renderer* r; hipStream_t st; int cls; hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(caster_renderer* r_, hipStream_t st_, int cls_) : r(r_), st(st_), cls(cls_) {
+    if (r->profiling) { a = take_event(r); b = take_event(r); (void)hipEventRecord(a, st); }
   }
   ~ScopedTimer() {
-    if (r->profiling) { (void)hipEventRecord(b, r->stream); r->pending_events.push_back({cls, a, b}); }
+    if (r->profiling) { (void)hipEventRecord(b, st); r->pending_events.push_back({cls, a, b}); }
   }
 };
 static void collect_timers(caster_renderer* r) {
@@ -411,55 +444,57 @@ static void collect_timers(caster_renderer* r) {
   r->pending_events.clear();
 }
 
-// Enqueues one batch of `n` iterations starting at `first`.
+// Enqueues one batch of `n` iterations starting at `first` on the next stream.
 static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   const DevScene& S = r->S;
-  hipStream_t st = r->stream;
-  LaunchCtx L = ctx_of(r);
+  Lane& ln = r->lanes[r->next_lane];
+  r->next_lane = (r->next_lane + 1) % (uint32_t)r->lanes.size();
+  hipStream_t st = ln.stream;
+  LaunchCtx L = ctx_of(r, ln);
   const uint32_t total = (uint32_t)S.slots_per_iter * n;
   const int walk_grid = r->walk_grid;
-  auto aux_for = [&](int which) { WalkAux a = r->aux; a.work = r->counters + 64 + which * kWorkShards * kWorkPad; return a; };
+  auto aux_for = [&](int which) { WalkAux a = ln.aux; a.work = ln.counters + 64 + which * kWorkShards * kWorkPad; return a; };
   const int shade_grid = r->shade_grid;
   const int gen_grid = (int)std::min<uint32_t>((total + kWave - 1) / kWave, (uint32_t)r->n_cu * 32);
   int cur = 0;
   {
-    ScopedTimer t(r, CASTER_K_GENERATE);
-    hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, r->ext[0], first, n, r->y0, r->y1);
+    ScopedTimer t(r, st, CASTER_K_GENERATE);
+    hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1);
   }
-  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, r->ext[0].count, total);
-  hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                     (const uint32_t*)nullptr, r->ext[1].count, r->shadow.count, r->probe.count, 0u, r->counters + 64,
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, total);
+  hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                     (const uint32_t*)nullptr, ln.ext[1].count, ln.shadow.count, ln.probe.count, 0u, ln.counters + 64,
                      3u * kWorkShards, r->work_init);
   const uint32_t live_rays = (uint32_t)S.width * (uint32_t)(r->y1 - r->y0) * n;
   auto bounce = [&](int b) {
-    RayQueue& q = r->ext[cur];
-    ShadeQueues out{r->ext[cur ^ 1], r->shadow, r->probe};
+    RayQueue& q = ln.ext[cur];
+    ShadeQueues out{ln.ext[cur ^ 1], ln.shadow, ln.probe};
     {
-      ScopedTimer t(r, CASTER_K_EXTEND);
+      ScopedTimer t(r, st, CASTER_K_EXTEND);
       hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, q, aux_for(0));
     }
     {
-      ScopedTimer t(r, CASTER_K_SHADE);
-      if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, r->stage);
+      ScopedTimer t(r, st, CASTER_K_SHADE);
+      if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
       else if (S.integrator == IT_VPT)
-        hipLaunchKernelGGL(k_shade_vpt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, r->stage, r->aux);
-      else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, r->stage);
+        hipLaunchKernelGGL(k_shade_vpt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage, ln.aux);
+      else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
     }
     if (S.integrator != IT_VPT) {
       {
-        ScopedTimer t(r, CASTER_K_SHADOW);
-        hipLaunchKernelGGL(k_trace<true>, dim3(walk_grid), dim3(kWave), 0, st, L, r->shadow, aux_for(1));
+        ScopedTimer t(r, st, CASTER_K_SHADOW);
+        hipLaunchKernelGGL(k_trace<true>, dim3(walk_grid), dim3(kWave), 0, st, L, ln.shadow, aux_for(1));
       }
       if (S.integrator == IT_PT) {
-        ScopedTimer t(r, CASTER_K_PROBE);
-        hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, r->probe, aux_for(2));
-        hipLaunchKernelGGL(k_probe_resolve, dim3(shade_grid), dim3(kWave), 0, st, L, r->probe);
+        ScopedTimer t(r, st, CASTER_K_PROBE);
+        hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, ln.probe, aux_for(2));
+        hipLaunchKernelGGL(k_probe_resolve, dim3(shade_grid), dim3(kWave), 0, st, L, ln.probe);
       }
     }
     // the camera queue also holds slots outside the image / row range: count only live rays
-    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, r->stats, (const uint32_t*)q.count,
-                       (const uint32_t*)r->shadow.count, (const uint32_t*)r->probe.count, q.count, r->shadow.count,
-                       r->probe.count, b == 0 ? live_rays : 0u, r->counters + 64, 3u * kWorkShards, r->work_init);
+    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)q.count,
+                       (const uint32_t*)ln.shadow.count, (const uint32_t*)ln.probe.count, q.count, ln.shadow.count,
+                       ln.probe.count, b == 0 ? live_rays : 0u, ln.counters + 64, 3u * kWorkShards, r->work_init);
     cur ^= 1;
   };
   if (S.integrator == IT_AO) {
@@ -474,16 +509,20 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
     for (; b < S.maxDepth; ++b) bounce(b);
     for (;; ++b) {
       uint32_t left = 0;
-      HIPCHECK(hipMemcpyAsync(&left, r->ext[cur].count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIPCHECK(hipMemcpyAsync(&left, ln.ext[cur].count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIPCHECK(hipStreamSynchronize(st));
       if (left == 0 || b > S.maxDepth + kMaxCrossings) break;
       bounce(b);
     }
   }
+  // a pixel's samples are added in iteration order whatever stream traced them
+  if (r->last_finish && r->last_finish != ln.finish_done) HIPCHECK(hipStreamWaitEvent(st, r->last_finish, 0));
   {
-    ScopedTimer t(r, CASTER_K_FINISH);
+    ScopedTimer t(r, st, CASTER_K_FINISH);
     hipLaunchKernelGGL(k_finish, dim3(r->n_cu * 8), dim3(256), 0, st, L, r->acc, n, r->y0, r->y1);
   }
+  HIPCHECK(hipEventRecord(ln.finish_done, st));
+  r->last_finish = ln.finish_done;
   HIPCHECK(hipGetLastError());
   return CASTER_OK;
 }
@@ -522,24 +561,32 @@ int caster_scene_get_info(const caster_scene* s, caster_scene_info* o) {
 void caster_end(caster_renderer* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+  for (Lane& ln : r->lanes) {
+    if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+    if (ln.finish_done) (void)hipEventDestroy(ln.finish_done);
+  }
   for (auto& t : r->pending_events) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (hipEvent_t e : r->free_events) (void)hipEventDestroy(e);
   for (void* p : r->allocs) (void)hipFree(p);
   delete r;
 }
 
-int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, caster_renderer** out) {
+int caster_begin_streams(const caster_scene* s, int device_id, int iters_in_flight, int n_streams,
+                         caster_renderer** out) {
   if (!s || !out) return fail(CASTER_ERR_ARG, "caster_begin: null argument");
   if (s->scene.prims.empty()) return fail(CASTER_ERR_SCENE, "caster_begin: scene has no primitives");
   for (const Prim& p : s->scene.prims)
     if (p.mat < 0 && s->scene.integrator == IT_PT)
       return fail(CASTER_ERR_SCENE, "caster_begin: a shape without a material needs the vpt integrator");
   caster_renderer* r = new caster_renderer();
-  int rc = begin_impl(s->scene, device_id, iters_in_flight, r);
+  int rc = begin_impl(s->scene, device_id, iters_in_flight, n_streams, r);
   if (rc) { caster_end(r); return rc; }
   *out = r;
   return CASTER_OK;
+}
+
+int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, caster_renderer** out) {
+  return caster_begin_streams(s, device_id, iters_in_flight, 0, out);
 }
 
 int caster_set_rows(caster_renderer* r, int y0, int y1) {
@@ -552,7 +599,10 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
   if (!r) return fail(CASTER_ERR_ARG, "caster_render: null renderer");
   HIPCHECK(hipSetDevice(r->device));
   if (reset) {
-    HIPCHECK(hipMemsetAsync(r->acc, 0, (size_t)r->S.width * r->S.height * 3 * sizeof(float), r->stream));
+    int rc = sync_lanes(r);
+    if (rc) return rc;
+    HIPCHECK(hipMemsetAsync(r->acc, 0, (size_t)r->S.width * r->S.height * 3 * sizeof(float), r->lanes[0].stream));
+    HIPCHECK(hipStreamSynchronize(r->lanes[0].stream));
     r->iterations = 0;
   }
   uint32_t done = 0;
@@ -570,7 +620,8 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
 int caster_sync(caster_renderer* r) {
   if (!r) return fail(CASTER_ERR_ARG, "caster_sync: null renderer");
   HIPCHECK(hipSetDevice(r->device));
-  HIPCHECK(hipStreamSynchronize(r->stream));
+  int rc = sync_lanes(r);
+  if (rc) return rc;
   collect_timers(r);
   return CASTER_OK;
 }
@@ -607,12 +658,15 @@ int caster_render(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int 
 int caster_read_film_device(caster_renderer* r, float* dev, int mode) {
   if (!r || !dev || mode < 0 || mode > 2) return fail(CASTER_ERR_ARG, "caster_read_film: bad argument");
   HIPCHECK(hipSetDevice(r->device));
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  hipStream_t st = r->lanes[0].stream;
   uint32_t npix = (uint32_t)r->S.width * (uint32_t)r->S.height;
   float div = mode == 2 ? 1.f : (float)(r->iterations ? r->iterations : 1u);
-  hipLaunchKernelGGL(k_resolve_film, dim3(r->n_cu * 4), dim3(256), 0, r->stream, (const float*)r->acc, dev, npix, div,
+  hipLaunchKernelGGL(k_resolve_film, dim3(r->n_cu * 4), dim3(256), 0, st, (const float*)r->acc, dev, npix, div,
                      mode == 1 ? 1 : 0, r->S.cam.filmic);
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipStreamSynchronize(r->stream));
+  HIPCHECK(hipStreamSynchronize(st));
   return CASTER_OK;
 }
 
@@ -631,10 +685,13 @@ __global__ void k_film_add(float* acc, const float* add, uint32_t n) {
 int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t n_iters) {
   if (!r || !sum_device) return fail(CASTER_ERR_ARG, "caster_film_add_device: null argument");
   HIPCHECK(hipSetDevice(r->device));
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  hipStream_t st = r->lanes[0].stream;
   uint32_t n = (uint32_t)r->S.width * (uint32_t)r->S.height * 3u;
-  hipLaunchKernelGGL(k_film_add, dim3(r->n_cu * 4), dim3(256), 0, r->stream, r->acc, sum_device, n);
+  hipLaunchKernelGGL(k_film_add, dim3(r->n_cu * 4), dim3(256), 0, st, r->acc, sum_device, n);
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipStreamSynchronize(r->stream));
+  HIPCHECK(hipStreamSynchronize(st));
   r->iterations += n_iters;
   return CASTER_OK;
 }
@@ -642,23 +699,27 @@ int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t
 int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   if (!r || !ids) return fail(CASTER_ERR_ARG, "caster_primary_ids: null argument");
   HIPCHECK(hipSetDevice(r->device));
-  LaunchCtx L = ctx_of(r);
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  Lane& ln = r->lanes[0];
+  hipStream_t st = ln.stream;
+  LaunchCtx L = ctx_of(r, ln);
   const uint32_t total = (uint32_t)r->S.slots_per_iter;
-  hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, r->stream, L, r->ext[0], iter, 1u,
+  hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, st, L, ln.ext[0], iter, 1u,
                      0, r->S.height);
-  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->ext[0].count, total);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, total);
   auto reset_work = [&]() {
-    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, r->stream, r->stats, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, 0u, r->counters + 64, 3u * kWorkShards, r->work_init);
+                       (uint32_t*)nullptr, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init);
   };
   reset_work();
-  hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid), dim3(kWave), 0, r->stream, L, r->ext[0], r->aux);
+  hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid), dim3(kWave), 0, st, L, ln.ext[0], ln.aux);
   reset_work();
-  hipLaunchKernelGGL(k_gather_ids, dim3(r->n_cu * 4), dim3(256), 0, r->stream, L, r->ext[0], r->ids);
-  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, r->stream, r->ext[0].count, 0u);
+  hipLaunchKernelGGL(k_gather_ids, dim3(r->n_cu * 4), dim3(256), 0, st, L, ln.ext[0], r->ids);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, 0u);
   HIPCHECK(hipGetLastError());
-  HIPCHECK(hipStreamSynchronize(r->stream));
+  HIPCHECK(hipStreamSynchronize(st));
   HIPCHECK(hipMemcpy(ids, r->ids, (size_t)r->S.width * r->S.height * sizeof(int32_t), hipMemcpyDeviceToHost));
   return CASTER_OK;
 }
@@ -666,21 +727,28 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
 int caster_get_stats(caster_renderer* r, caster_stats* out) {
   if (!r || !out) return fail(CASTER_ERR_ARG, "caster_get_stats: null argument");
   HIPCHECK(hipSetDevice(r->device));
-  HIPCHECK(hipStreamSynchronize(r->stream));
-  Stats st;
-  HIPCHECK(hipMemcpy(&st, r->stats, sizeof(Stats), hipMemcpyDeviceToHost));
-  for (int i = 0; i < 4; ++i) out->rays[i] = st.rays[i];
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  for (int i = 0; i < 4; ++i) out->rays[i] = 0;
+  out->invalid = 0;
+  out->stack_overflow = 0;
+  for (Lane& ln : r->lanes) {
+    Stats st;
+    HIPCHECK(hipMemcpy(&st, ln.stats, sizeof(Stats), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out->rays[i] += st.rays[i];
+    out->invalid += st.invalid;
+    out->stack_overflow += st.stack_overflow;
+  }
   out->samples = r->samples;
-  out->invalid = st.invalid;
-  out->stack_overflow = st.stack_overflow;
   return CASTER_OK;
 }
 
 int caster_reset_stats(caster_renderer* r) {
   if (!r) return fail(CASTER_ERR_ARG, "caster_reset_stats: null renderer");
   HIPCHECK(hipSetDevice(r->device));
-  HIPCHECK(hipStreamSynchronize(r->stream));
-  HIPCHECK(hipMemset(r->stats, 0, sizeof(Stats)));
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  for (Lane& ln : r->lanes) HIPCHECK(hipMemset(ln.stats, 0, sizeof(Stats)));
   r->samples = 0;
   return CASTER_OK;
 }

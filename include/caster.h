@@ -64,6 +64,15 @@ int caster_scene_get_info(const caster_scene* s, caster_scene_info* out);
    0 picks a default. */
 int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, caster_renderer** out);
 
+/* caster_begin with the number of HIP streams stated.  Successive batches are
+   dealt to the streams in turn and overlap on the GPU (each stream owns a path
+   pool of `iters_in_flight` iterations; the film is still accumulated in
+   iteration order, so the image does not depend on `n_streams`).  0 picks the
+   default (2); at most 8.  No counterpart in the reference, whose Render
+   synchronises the device after every sample (pathtracer.cu:2739). */
+int caster_begin_streams(const caster_scene* s, int device_id, int iters_in_flight, int n_streams,
+                         caster_renderer** out);
+
 /* Restricts this renderer to scanlines [y0, y1) of the image (tile sharding
    across GPUs).  Default is the whole image. */
 int caster_set_rows(caster_renderer* r, int y0, int y1);
@@ -75,7 +84,7 @@ int caster_set_rows(caster_renderer* r, int y0, int y1);
    `reset`, pathtracer.cu:2507).  Returns after the GPU has finished. */
 int caster_render(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset);
 
-/* Same, but only enqueues the work on the renderer's stream (no host
+/* Same, but only enqueues the work on the renderer's streams (no host
    synchronisation); pair with caster_sync. */
 int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset);
 int caster_sync(caster_renderer* r);

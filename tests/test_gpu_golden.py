@@ -42,20 +42,25 @@ def test_against_golden(caster, key):
     r.close()
 
 
-def test_batching_and_call_splitting_do_not_change_bits(caster):
+def test_batching_streams_and_call_splitting_do_not_change_bits(caster):
+    """The film is accumulated in iteration order whatever the batch size, the number of
+    HIP streams the batches are dealt to, and the way the calls split the iterations."""
     sc = caster.Scene(os.path.join(GOLD, "scenes", "stairs_pt", "scene.json"))
     films = []
-    for inflight, chunks in ((1, [(1, 8)]), (8, [(1, 8)]), (3, [(1, 5), (6, 3)])):
-        r = caster.Renderer(sc, 0, inflight)
-        first = True
+    for inflight, streams, chunks in ((1, 1, [(1, 8)]), (8, 1, [(1, 8)]), (3, 2, [(1, 5), (6, 3)]),
+                                      (1, 3, [(1, 8)]), (2, 2, [(1, 1), (2, 7)]), (1, 8, [(1, 8)])):
+        r = caster.Renderer(sc, 0, inflight, streams)
+        r.render(1, 0, True)
         for f, n in chunks:
-            r.render(f, n, first)
-            first = False
+            r.render_async(f, n, False)   # no host synchronisation between the calls
+        r.sync()
         assert r.iterations == 8
         films.append(r.read_film(2))
+        st = r.stats()
+        assert st["stack_overflow"] == 0 and st["samples"] == sc.width * sc.height * 8
         r.close()
-    np.testing.assert_array_equal(films[0], films[1])
-    np.testing.assert_array_equal(films[0], films[2])
+    for f in films[1:]:
+        np.testing.assert_array_equal(films[0], f)
 
 
 def test_tile_and_spp_sharding_on_one_gpu(caster):
