@@ -319,9 +319,28 @@ struct Stack {
   uint32_t stride;
   int sp;
 };
+#ifndef CASTER_STACK_SPLIT
+#define CASTER_STACK_SPLIT 1
+#endif
+#if CASTER_STACK_SPLIT
+// The LDS entries are accessed as one volatile 64-bit word: that keeps each push
+// and pop a single ds_write_b64 / ds_read_b64, where the optimiser would
+// otherwise merge the LDS and the spill branch into 32-bit flat accesses.
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64_t;
+__device__ inline void lds_put(Stack& s, int sp, uint32_t lane, uint2 e) {
+  *(lds_u64_t*)&s.lds[sp][lane] = ((unsigned long long)e.y << 32) | e.x;
+}
+__device__ inline uint2 lds_get(Stack& s, int sp, uint32_t lane) {
+  unsigned long long v = *(lds_u64_t*)&s.lds[sp][lane];
+  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+#else
+__device__ inline void lds_put(Stack& s, int sp, uint32_t lane, uint2 e) { s.lds[sp][lane] = e; }
+__device__ inline uint2 lds_get(Stack& s, int sp, uint32_t lane) { return s.lds[sp][lane]; }
+#endif
 __device__ inline bool stack_push(Stack& s, uint32_t lane, int ref, float tn) {
   uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
-  if (s.sp < kLdsDepth) s.lds[s.sp][lane] = e;
+  if (s.sp < kLdsDepth) lds_put(s, s.sp, lane, e);
   else if (s.sp < kLdsDepth + kSpillDepth) s.spill[(size_t)(s.sp - kLdsDepth) * s.stride] = e;
   else return false;
   ++s.sp;
@@ -334,7 +353,9 @@ __device__ inline bool stack_push(Stack& s, uint32_t lane, int ref, float tn) {
 __device__ inline int stack_next(Stack& s, uint32_t lane, float tmax) {
   while (s.sp > 0) {
     --s.sp;
-    uint2 e = s.sp < kLdsDepth ? s.lds[s.sp][lane] : s.spill[(size_t)(s.sp - kLdsDepth) * s.stride];
+    uint2 e;
+    if (s.sp < kLdsDepth) e = lds_get(s, s.sp, lane);
+    else e = s.spill[(size_t)(s.sp - kLdsDepth) * s.stride];
     if (!(__uint_as_float(e.y) > tmax)) return (int)e.x;
   }
   return kRefEmpty;
@@ -477,9 +498,19 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 #ifndef CASTER_TRACE_WAVES
 #define CASTER_TRACE_WAVES 5
 #endif
+#ifdef CASTER_WALK_STATS
+// tuning aid: wavefront-level step counts of k_trace, [ANY][counter]
+__device__ unsigned long long g_walk_stats[2][8];
+#define CASTER_WS(i, v) ws[i] += (unsigned long long)(v)
+#else
+#define CASTER_WS(i, v)
+#endif
 template <bool ANY>
 __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
+#ifdef CASTER_WALK_STATS
+  unsigned long long ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   const DevScene& S = L.S;
   const uint32_t lane = threadIdx.x;
   const uint32_t count = *q.count;
@@ -565,6 +596,7 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
         chunk_next += give;
       }
     }
+    CASTER_WS(6, 1);
     if (!__any(idx >= 0)) {
       if (!more) break;
       continue;
@@ -590,9 +622,15 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
       int n_free = kWave - __popcll(m_busy);
       if (m_busy == 0) break;
       if (more && n_free >= kRefillIdle) break;
+      CASTER_WS(4, __popcll(m_busy));
+      CASTER_WS(5, __popcll(m_inner & m_leaf));
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
+        CASTER_WS(0, 1);
+        CASTER_WS(1, n_inner);
         if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
       } else if (pend != kRefEmpty) {
+        CASTER_WS(2, 1);
+        CASTER_WS(3, n_leaf);
         int i = ~pend;
         float t, b1, b2;
         bool last;
@@ -638,6 +676,10 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
 #endif
     }
   }
+#ifdef CASTER_WALK_STATS
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_walk_stats[ANY ? 1 : 0][k], ws[k]);
+#endif
 }
 
 // -------------------------------------------------------------- shading data

@@ -755,4 +755,15 @@ int caster_reset_stats(caster_renderer* r) {
 
 uint32_t caster_iterations(const caster_renderer* r) { return r ? r->iterations : 0; }
 
+#ifdef CASTER_WALK_STATS
+// tuning builds only: copies and clears the k_trace step counters
+int caster_debug_walk_stats(unsigned long long* out16) {
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_walk_stats), 16 * sizeof(unsigned long long)));
+  unsigned long long zero[16] = {0};
+  HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stats), zero, sizeof(zero)));
+  return CASTER_OK;
+}
+#endif
+
 }  // extern "C"
