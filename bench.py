@@ -59,6 +59,20 @@ def algorithmic_bytes_per_ray(counts, kind):
             + 32.0 * counts["lines"][kind]) / rays
 
 
+def pmc_traffic_per_launch(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_pmc.json: per-dispatch averages of FETCH_SIZE and WRITE_SIZE, in KiB).
+    FETCH_SIZE counts half the bytes on gfx950, for 16-byte-per-lane streaming reads and for the
+    128-byte record gathers of the traversal alike (tools/calib/fetch_calib.hip measures both
+    against known byte counts), so it is doubled; WRITE_SIZE is exact.  None without the file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+            k = json.load(f)[kernel]
+        return (2.0 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,24 +230,29 @@ def main():
                 "single_thread_msamples_per_s": c1.samples / tc1 / 1e6,
                 "mrays_per_s": sum(counts["rays"]) / tc / 1e6,
             }
-        # roofline of the dominant kernel
-        walk = {"extend": 0, "shadow": 1, "probe": 2}
-        dom = max(walk, key=lambda k: kt[k][0])
-        ms, launches = kt[dom]
-        roof = {"bound": "hbm", "kernel": "k_" + dom, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+        # roofline of the dominant kernel, by kernel symbol as rocprofv3 reports it:
+        # k_trace<false> runs the extension and the probe rays, k_trace<true> the shadow rays
+        symbols = {"k_trace<false>": (("extend", 0), ("probe", 2)), "k_trace<true>": (("shadow", 1),)}
+        dom = max(symbols, key=lambda k: sum(kt[c][0] for c, _ in symbols[k]))
+        ms = sum(kt[c][0] for c, _ in symbols[dom])
+        launches = sum(kt[c][1] for c, _ in symbols[dom])
+        roof = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "traffic": pmc_traffic_per_launch(dom),
                 "avg_launch_ms": ms / max(launches, 1), "launches": launches}
         if counts is not None and ms > 0:
-            kind = walk[dom]
-            per_ray = algorithmic_bytes_per_ray(counts, kind)
-            record = {"extend": 32 + 16, "shadow": 32 + 4, "probe": 32 + 4 + 16}[dom]
-            # this rank's rays of that kind in the timed region
-            n_rays = st["rays"][kind]
-            achieved = n_rays * (per_ray + record) / (ms * 1e-3) / 1e9
+            record = {"extend": 32 + 16, "shadow": 32 + 4, "probe": 32 + 4 + 16}
+            # this rank's rays of those kinds in the timed region x the oracle's bytes per ray of that kind
+            alg = sum(st["rays"][kind] * (algorithmic_bytes_per_ray(counts, kind) + record[c])
+                      for c, kind in symbols[dom])
+            n_rays = sum(st["rays"][kind] for _, kind in symbols[dom])
+            o_rays = sum(counts["rays"][kind] for _, kind in symbols[dom])
+            achieved = alg / (ms * 1e-3) / 1e9
             roof.update(achieved=achieved, frac=achieved / HBM_PEAK_GBS,
-                        algorithmic_bytes_per_ray=per_ray + record,
+                        algorithmic_bytes_per_ray=alg / max(n_rays, 1),
+                        algorithmic_bytes_per_launch=alg / max(launches, 1),
                         rays_per_launch=n_rays / max(launches, 1),
-                        nodes_per_ray=counts["nodes"][kind] / max(counts["rays"][kind], 1),
-                        tris_per_ray=counts["tris"][kind] / max(counts["rays"][kind], 1))
+                        nodes_per_ray=sum(counts["nodes"][kind] for _, kind in symbols[dom]) / max(o_rays, 1),
+                        tris_per_ray=sum(counts["tris"][kind] for _, kind in symbols[dom]) / max(o_rays, 1))
         else:
             roof.update(achieved=None, frac=None)
         out["roofline"] = roof

@@ -486,8 +486,10 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
         hipLaunchKernelGGL(k_trace<true>, dim3(walk_grid), dim3(kWave), 0, st, L, ln.shadow, aux_for(1));
       }
       if (S.integrator == IT_PT) {
-        ScopedTimer t(r, st, CASTER_K_PROBE);
-        hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, ln.probe, aux_for(2));
+        {
+          ScopedTimer t(r, st, CASTER_K_PROBE);
+          hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, ln.probe, aux_for(2));
+        }
         hipLaunchKernelGGL(k_probe_resolve, dim3(shade_grid), dim3(kWave), 0, st, L, ln.probe);
       }
     }

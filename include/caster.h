@@ -108,8 +108,11 @@ int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t
 int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids);
 
 /* Per-kernel-class device time, measured with HIP events recorded on the
-   renderer's own stream around every launch (no counterpart in the
-   reference, which measures nothing).  Enabling resets the totals. */
+   renderer's own streams around every launch of the class's kernel (extend,
+   shadow and probe each bracket exactly one traversal launch; with more than
+   one stream a launch shares the GPU with the other stream's kernels while it
+   runs).  No counterpart in the reference, which measures nothing.  Enabling
+   resets the totals. */
 enum {
   CASTER_K_GENERATE = 0, CASTER_K_EXTEND, CASTER_K_SHADE, CASTER_K_SHADOW, CASTER_K_PROBE, CASTER_K_FINISH,
   CASTER_N_KERNEL_CLASSES
