@@ -21,7 +21,7 @@ namespace caster {
 
 constexpr int kWave = 64;
 #ifndef CASTER_LDS_DEPTH
-#define CASTER_LDS_DEPTH 12
+#define CASTER_LDS_DEPTH 10
 #endif
 #ifndef CASTER_REFILL
 #define CASTER_REFILL 24
@@ -36,6 +36,14 @@ constexpr int kWave = 64;
 #define CASTER_VOTE_NUM 1
 #define CASTER_VOTE_DEN 1
 #endif
+#ifndef CASTER_TRACE_BLOCK_WAVES
+#define CASTER_TRACE_BLOCK_WAVES 1
+#endif
+#ifndef CASTER_TOP_NODES
+#define CASTER_TOP_NODES 21
+#endif
+constexpr int kTraceBlockWaves = CASTER_TRACE_BLOCK_WAVES;  // wavefronts per traversal workgroup (they share the LDS copy of the top of the tree)
+constexpr int kTopNodes = CASTER_TOP_NODES;                 // 4-wide nodes, in breadth-first order from the root, kept in LDS
 constexpr int kLdsDepth = CASTER_LDS_DEPTH;  // traversal-stack entries per lane kept in LDS
 constexpr int kSpillDepth = 48;              // further entries in a per-lane column in HBM
 constexpr uint32_t kChunk = CASTER_CHUNK;        // rays a wavefront claims from a queue per atomic
@@ -363,10 +371,26 @@ __device__ inline int stack_next(Stack& s, uint32_t lane, float tmax) {
 
 // One 4-wide node: four slab tests, the children that pass sorted nearest
 // first; the nearest is returned, the others are deferred.
+// Nodes below `n_top` are read from the workgroup's LDS copy `top` (7 x 16 B
+// per node) instead of through the vector memory pipeline.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f_t lds_v4f_t;
+__device__ inline float4 lds_f4(const float4* p) {
+  v4f_t v = *(const lds_v4f_t*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+constexpr int kTopF4 = 7;
 __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float tmax, Stack& st, uint32_t lane,
-                                unsigned long long* overflow) {
-  const float4* n = S.nodes + (size_t)cur * kNodeF4;
-  float4 lx = n[0], ly = n[1], lz = n[2], hx = n[3], hy = n[4], hz = n[5], rf = n[6];
+                                unsigned long long* overflow, const float4* top = nullptr, int n_top = 0) {
+  float4 lx, ly, lz, hx, hy, hz, rf;
+  if (cur < n_top) {
+    const float4* n = top + cur * kTopF4;
+    lx = lds_f4(n); ly = lds_f4(n + 1); lz = lds_f4(n + 2); hx = lds_f4(n + 3); hy = lds_f4(n + 4); hz = lds_f4(n + 5);
+    rf = lds_f4(n + 6);
+  } else {
+    const float4* n = S.nodes + (size_t)cur * kNodeF4;
+    lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; rf = n[6];
+  }
   int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
   float k0, k1, k2, k3;
   bool h0 = box_test(v3(lx.x, ly.x, lz.x), v3(hx.x, hy.x, hz.x), o, inv, tmax, S.box_scale, k0) && r0 != kRefEmpty;
@@ -506,16 +530,26 @@ __device__ unsigned long long g_walk_stats[2][8];
 #define CASTER_WS(i, v)
 #endif
 template <bool ANY>
-__global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
-  __shared__ uint2 s_stack[kLdsDepth][kWave];
+__global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
+  __shared__ uint2 s_stack[kTraceBlockWaves][kLdsDepth][kWave];
+  __shared__ float4 s_top[kTopNodes > 0 ? kTopNodes * kTopF4 : 1];
 #ifdef CASTER_WALK_STATS
   unsigned long long ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const DevScene& S = L.S;
-  const uint32_t lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave_in_block = threadIdx.x >> 6;
+  const uint32_t wave_id = blockIdx.x * kTraceBlockWaves + wave_in_block;  // index of this wavefront in the grid
   const uint32_t count = *q.count;
   unsigned long long* overflow = &L.stats->stack_overflow;
-  Stack st{s_stack, aux.spill + (blockIdx.x * kWave + lane), aux.spill_stride, 0};
+  // the top of the tree, shared by the workgroup's wavefronts
+  const int n_top = S.n_nodes < kTopNodes ? S.n_nodes : kTopNodes;
+  if (kTopNodes > 0) {
+    for (int i = (int)threadIdx.x; i < n_top * kTopF4; i += kWave * kTraceBlockWaves)
+      s_top[i] = S.nodes[(size_t)(i / kTopF4) * kNodeF4 + (i % kTopF4)];
+    __syncthreads();
+  }
+  Stack st{s_stack[wave_in_block], aux.spill + (wave_id * kWave + lane), aux.spill_stride, 0};
   int idx = -1;
   int cur = kRefEmpty;
   int pend = kRefEmpty;  // a leaf waiting for its primitives to be tested
@@ -527,11 +561,11 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
   // this wavefront's first chunk is assigned statically (no atomic storm at
   // launch): the work counters start at the end of the static assignment
   const uint32_t part = ((count + kWorkShards - 1) / kWorkShards + kWave - 1) / kWave * kWave;
-  uint32_t shard = blockIdx.x % kWorkShards, shards_tried = 0;
+  uint32_t shard = wave_id % kWorkShards, shards_tried = 0;
   uint32_t chunk_next, chunk_end;
   {
     uint32_t lo = shard * part, hi = lo + part < count ? lo + part : count;
-    uint32_t base = (blockIdx.x / kWorkShards) * kChunk;
+    uint32_t base = (wave_id / kWorkShards) * kChunk;
     chunk_next = lo + base < hi ? lo + base : 0;
     chunk_end = lo + base < hi ? (chunk_next + kChunk < hi ? chunk_next + kChunk : hi) : 0;
   }
@@ -627,7 +661,7 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
         CASTER_WS(0, 1);
         CASTER_WS(1, n_inner);
-        if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
+        if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow, s_top, n_top);
       } else if (pend != kRefEmpty) {
         CASTER_WS(2, 1);
         CASTER_WS(3, n_leaf);
@@ -657,7 +691,7 @@ __global__ __launch_bounds__(kWave, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L
       if (n_inner + n_leaf == 0) break;
       if (more && n_free >= kRefillIdle) break;
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
-        if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
+        if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow, s_top, n_top);
       } else if (cur < 0 && cur != kRefEmpty) {
         int i = ~cur;
         float t, b1, b2;

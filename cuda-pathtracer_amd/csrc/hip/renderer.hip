@@ -122,6 +122,39 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
       d[6] = make_float4(as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]));
     }
   }
+  // The first kTopNodes nodes in breadth-first order from the root come first in
+  // the array (the traversal kernel keeps them in LDS); the others keep their
+  // depth-first order.
+  {
+    const int n_nodes = (int)(A.nodes.size() / kNodeF4);
+    std::vector<int> order;
+    std::vector<char> taken((size_t)n_nodes, 0);
+    if (n_nodes > 0) { order.push_back(0); taken[0] = 1; }
+    for (size_t head = 0; head < order.size() && (int)order.size() < kTopNodes; ++head) {
+      const float4 rf = A.nodes[(size_t)order[head] * kNodeF4 + 6];
+      const float refs[4] = {rf.x, rf.y, rf.z, rf.w};
+      for (int k = 0; k < 4 && (int)order.size() < kTopNodes; ++k) {
+        int ref; memcpy(&ref, &refs[k], 4);
+        if (ref >= 0 && !taken[ref]) { order.push_back(ref); taken[ref] = 1; }
+      }
+    }
+    for (int i = 0; i < n_nodes; ++i)
+      if (!taken[i]) order.push_back(i);
+    std::vector<int> new_id((size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) new_id[order[i]] = i;
+    std::vector<float4> moved(A.nodes.size());
+    for (int i = 0; i < n_nodes; ++i) {
+      const float4* src = &A.nodes[(size_t)order[i] * kNodeF4];
+      float4* dst = &moved[(size_t)i * kNodeF4];
+      for (int k = 0; k < kNodeF4; ++k) dst[k] = src[k];
+      float* refs = &dst[6].x;
+      for (int k = 0; k < 4; ++k) {
+        int ref; memcpy(&ref, &refs[k], 4);
+        if (ref >= 0) { ref = new_id[ref]; memcpy(&refs[k], &ref, 4); }
+      }
+    }
+    A.nodes.swap(moved);
+  }
   for (size_t i = 0; i < np; ++i) {
     const Prim& p = sc.prims[i];
     float4* ir = &A.isect[i * kIsectF4];
@@ -395,9 +428,11 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   }
   // persistent traversal grid: as many wavefronts as LDS stacks and registers allow per CU
   {
-    int by_lds = (160 * 1024) / (kLdsDepth * kWave * 8);
-    int by_regs = CASTER_TRACE_WAVES * 4;
-    r->walk_grid = r->n_cu * std::min(by_lds, by_regs);
+    // per workgroup: kTraceBlockWaves stacks and one copy of the top of the tree
+    int lds_per_block = kTraceBlockWaves * kLdsDepth * kWave * 8 + std::max(kTopNodes, 1) * kTopF4 * 16;
+    int by_lds = (160 * 1024) / lds_per_block * kTraceBlockWaves;
+    int by_regs = CASTER_TRACE_WAVES * 4 / kTraceBlockWaves * kTraceBlockWaves;
+    r->walk_grid = r->n_cu * std::max(kTraceBlockWaves, std::min(by_lds, by_regs));
   }
   r->work_init = ((uint32_t)r->walk_grid + kWorkShards - 1) / kWorkShards * kChunk;
   r->lanes.resize((size_t)n_streams);
@@ -471,7 +506,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
     ShadeQueues out{ln.ext[cur ^ 1], ln.shadow, ln.probe};
     {
       ScopedTimer t(r, st, CASTER_K_EXTEND);
-      hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, q, aux_for(0));
+      hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, q, aux_for(0));
     }
     {
       ScopedTimer t(r, st, CASTER_K_SHADE);
@@ -483,12 +518,12 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
     if (S.integrator != IT_VPT) {
       {
         ScopedTimer t(r, st, CASTER_K_SHADOW);
-        hipLaunchKernelGGL(k_trace<true>, dim3(walk_grid), dim3(kWave), 0, st, L, ln.shadow, aux_for(1));
+        hipLaunchKernelGGL(k_trace<true>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.shadow, aux_for(1));
       }
       if (S.integrator == IT_PT) {
         {
           ScopedTimer t(r, st, CASTER_K_PROBE);
-          hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid), dim3(kWave), 0, st, L, ln.probe, aux_for(2));
+          hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.probe, aux_for(2));
         }
         hipLaunchKernelGGL(k_probe_resolve, dim3(shade_grid), dim3(kWave), 0, st, L, ln.probe);
       }
@@ -716,7 +751,7 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
                        (uint32_t*)nullptr, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init);
   };
   reset_work();
-  hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid), dim3(kWave), 0, st, L, ln.ext[0], ln.aux);
+  hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.ext[0], ln.aux);
   reset_work();
   hipLaunchKernelGGL(k_gather_ids, dim3(r->n_cu * 4), dim3(256), 0, st, L, ln.ext[0], r->ids);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, 0u);
