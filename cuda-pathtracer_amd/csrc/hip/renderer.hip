@@ -236,7 +236,7 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
   }
 }
 
-constexpr int kDefaultStreams = 2;
+constexpr int kDefaultStreams = 3;
 constexpr int kMaxStreams = 8;
 
 static float gamma_n(int n) {  // common.h:111-114: double arithmetic, float result
@@ -409,8 +409,9 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
 
   if (iters_in_flight <= 0) {
     // late bounces keep few rays alive: a batch needs tens of millions of paths
-    // for their launches to fill the chip
-    long long target = 32ll << 20;
+    // for their launches to fill the chip (the pools are sized for 288 GB of HBM:
+    // 64 M slots x 380 B per stream)
+    long long target = 64ll << 20;
     iters_in_flight = (int)std::max<long long>(1, std::min<long long>(64, target / S.slots_per_iter));
   }
   if (n_streams <= 0) n_streams = kDefaultStreams;

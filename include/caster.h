@@ -68,7 +68,7 @@ int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, cast
    dealt to the streams in turn and overlap on the GPU (each stream owns a path
    pool of `iters_in_flight` iterations; the film is still accumulated in
    iteration order, so the image does not depend on `n_streams`).  0 picks the
-   default (2); at most 8.  No counterpart in the reference, whose Render
+   default (3); at most 8.  No counterpart in the reference, whose Render
    synchronises the device after every sample (pathtracer.cu:2739). */
 int caster_begin_streams(const caster_scene* s, int device_id, int iters_in_flight, int n_streams,
                          caster_renderer** out);
