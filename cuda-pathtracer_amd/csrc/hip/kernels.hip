@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kWave) void k_generate(LaunchCtx L, RayQueue q, uin
     uint32_t px, py;
     bool live = slot_pixel(S, local, px, py) && (int)py >= y0 && (int)py < y1;
     uint32_t iter = first_iter + k;
-    float4 o4 = make_float4(0, 0, 0, 0), d4 = make_float4(0, 0, 1, -1.f);
+    float4 o4 = make_float4(0, 0, 0, __int_as_float(-1)), d4 = make_float4(0, 0, 1, -1.f);
     uint32_t rng = 1u;
     if (live) {
       uint32_t pixel = px + py * (uint32_t)S.width;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(kWave) void k_generate(LaunchCtx L, RayQueue q, uin
       float a2 = rng_uniform(rng);
       V3 orig, dir;
       primary_ray(S.cam, px + offsetx, py + offsety, a1, a2, orig, dir);
-      o4 = f4(orig, S.epsilon);
+      o4 = f4(orig, __int_as_float(-1));
       d4 = f4(dir, INFINITY);
     }
     uint32_t flags = 0;
@@ -554,7 +554,8 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
   int cur = kRefEmpty;
   int pend = kRefEmpty;  // a leaf waiting for its primitives to be tested
   V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 1);
-  float tmin = 0.f, maxD = 1.f;
+  const float tmin = S.epsilon;
+  float maxD = 1.f;
   Hit hit;
   hit.t = 0.f; hit.prim = -1; hit.b1 = hit.b2 = 0.f;
   bool occluded = false;
@@ -618,10 +619,11 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
           idx = (int)(chunk_next + prefix);
           float4 o4 = q.o[idx], d4 = q.d[idx];
           o = v3(o4); d = v3(d4);
-          tmin = o4.w;
           inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
           maxD = maxcomp(vabs(d));
-          hit.t = d4.w; hit.prim = -1; hit.b1 = hit.b2 = 0.f;
+          // every queued ray starts at the scene's epsilon; o.w carries a hit known
+          // beforehand (a probe ray's nearest emitter, at distance tmax) or -1
+          hit.t = d4.w; hit.prim = __float_as_int(o4.w); hit.b1 = hit.b2 = 0.f;
           occluded = false;
           st.sp = 0;
           // tmax < 0 marks a camera slot outside the image: nothing to trace
@@ -1235,13 +1237,13 @@ struct StageArea {
   uint32_t region_cap;           // entries per wavefront region
 };
 __device__ inline void stage_push(const RayQueue& stage, uint32_t base, uint32_t& n, bool want, int slot, V3 o,
-                                  float tmin, V3 d, float tmax) {
+                                  int seed, V3 d, float tmax) {
   unsigned long long mask = __ballot(want);
   if (mask == 0) return;
   uint32_t lane = threadIdx.x & 63u;
   if (want) {
     uint32_t at = base + n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    stage.o[at] = f4(o, tmin);
+    stage.o[at] = f4(o, __int_as_float(seed));
     stage.d[at] = f4(d, tmax);
     stage.slot[at] = slot;
   }
@@ -1284,6 +1286,10 @@ __device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li) {
 #ifndef CASTER_SHADE_WAVES
 #define CASTER_SHADE_WAVES 4
 #endif
+#ifndef CASTER_PROBE_CULL
+#define CASTER_PROBE_CULL 1
+#endif
+constexpr int kProbeCullLights = 8;  // emitter triangles tested directly before a probe ray is sent
 __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
   const DevScene& S = L.S;
   const PathState& P = L.P;
@@ -1298,7 +1304,8 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
     int slot = 0;
     bool want_next = false, want_shadow = false, want_probe = false;
     V3 no = v3(0, 0, 0), nd = v3(0, 0, 1), so = no, sd = nd, po = no, pd = nd;
-    float stmax = 0.f;
+    float stmax = 0.f, ptmax = INFINITY;
+    int pseed = -1;
     if (active) {
       slot = cur.slot[idx];
       float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
@@ -1373,6 +1380,28 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
               po = pos; pd = mo;
               py = f4(mfr, mpdf);
               absdot = fabsf(dot(mo, nor));
+#if CASTER_PROBE_CULL
+              // The probe only contributes when its closest hit is an emitter (no
+              // environment light here).  With few emitters their triangles are
+              // tested first, with the very test the traversal uses: if none is
+              // hit, the closest hit cannot be one and no ray is sent; otherwise
+              // the ray starts out holding the nearest emitter hit, so that the
+              // traversal only looks for something at least as close.
+              if (!S.inf.valid && S.n_lights <= kProbeCullLights) {
+                float pmaxD = maxcomp(vabs(mo));
+                for (int li = 0; li < S.n_lights; ++li) {
+                  int lprim = __float_as_int(S.lights[(size_t)li * kLightF4 + 4].w);
+                  float t, b1, b2;
+                  bool last;
+                  if (prim_test(S, lprim, pos, mo, pmaxD, S.epsilon, INFINITY, t, b1, b2, last) &&
+                      (t < ptmax || (t == ptmax && lprim > pseed) || pseed < 0)) {
+                    ptmax = t;
+                    pseed = lprim;
+                  }
+                }
+                if (pseed < 0) { want_probe = false; py = make_float4(0, 0, 0, 0); }
+              }
+#endif
             }
             P.pend_x[slot] = f4(x, absdot);
             P.pend_y[slot] = py;
@@ -1405,9 +1434,9 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
       P.beta_rng[slot] = f4(beta, rng);
       P.li_flags[slot] = f4(Li, flags);
     }
-    stage_push(stage.next, sbase, n_next, want_next, slot, no, S.epsilon, nd, INFINITY);
-    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, S.epsilon, sd, stmax);
-    stage_push(stage.probe, sbase, n_probe, want_probe, slot, po, S.epsilon, pd, INFINITY);
+    stage_push(stage.next, sbase, n_next, want_next, slot, no, -1, nd, INFINITY);
+    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, -1, sd, stmax);
+    stage_push(stage.probe, sbase, n_probe, want_probe, slot, po, pseed, pd, ptmax);
   }
   __syncthreads();  // the copy below reads what other lanes of this wavefront staged
   stage_flush(stage.next, sbase, n_next, out.next);
@@ -1439,6 +1468,14 @@ __global__ __launch_bounds__(kWave) void k_probe_resolve(LaunchCtx L, RayQueue q
       if (type == 0u && light != -1) {
         LightRec l;
         load_light(S, light, l);
+        // a hit the ray started out with carries no barycentrics: the same test gives them again
+        {
+          float t, b1, b2;
+          bool last;
+          if (prim_test(S, h.prim, pos, out, maxcomp(vabs(out)), S.epsilon, INFINITY, t, b1, b2, last)) {
+            h.b1 = b1; h.b2 = b2;
+          }
+        }
         const float4* sh = S.shade + (size_t)h.prim * kShadeF4;
         V3 n = normalize(v3(sh[0]) * (1.f - h.b1 - h.b2) + v3(sh[1]) * h.b1 + v3(sh[2]) * h.b2);
         V3 p = pos + h.t * out;
@@ -1519,7 +1556,7 @@ __global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, S
         P.li_flags[slot] = f4(Li, flags);
       }
     }
-    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, S.epsilon, sd, S.maxDist);
+    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, -1, sd, S.maxDist);
   }
   __syncthreads();
   stage_flush(stage.shadow, sbase, n_shadow, out.shadow);
@@ -1786,7 +1823,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
         P.beta_prev[slot] = make_float4(0, 0, 0, __uint_as_float((uint32_t)crossings));
       }
     }
-    stage_push(stage.next, sbase, n_next, want_next, slot, no, S.epsilon, nd, INFINITY);
+    stage_push(stage.next, sbase, n_next, want_next, slot, no, -1, nd, INFINITY);
   }
   __syncthreads();
   stage_flush(stage.next, sbase, n_next, out.next);
