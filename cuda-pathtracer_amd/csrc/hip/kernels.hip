@@ -380,6 +380,7 @@ __device__ inline float4 lds_f4(const float4* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 constexpr int kTopF4 = 7;
+template <bool SORT = true>
 __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float tmax, Stack& st, uint32_t lane,
                                 unsigned long long* overflow, const float4* top = nullptr, int n_top = 0) {
   float4 lx, ly, lz, hx, hy, hz, rf;
@@ -405,11 +406,28 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
     float tk_ = ka; ka = kb; kb = tk_;       \
     int tr_ = ra; ra = rb; rb = tr_;         \
   }
-  CASTER_CSWAP(k0, r0, k1, r1)
-  CASTER_CSWAP(k2, r2, k3, r3)
-  CASTER_CSWAP(k0, r0, k2, r2)
-  CASTER_CSWAP(k1, r1, k3, r3)
-  CASTER_CSWAP(k1, r1, k2, r2)
+  if (SORT) {
+    CASTER_CSWAP(k0, r0, k1, r1)
+    CASTER_CSWAP(k2, r2, k3, r3)
+    CASTER_CSWAP(k0, r0, k2, r2)
+    CASTER_CSWAP(k1, r1, k3, r3)
+    CASTER_CSWAP(k1, r1, k2, r2)
+  } else {
+    // any-hit rays: children that are hit first, in no particular order (the network
+    // sorts the hit flags; an exchange moves a miss behind a hit)
+#define CASTER_CMOVE(ha, ka, ra, hb, kb, rb)              \
+    if (!ha && hb) {                                       \
+      float tk_ = ka; ka = kb; kb = tk_;                   \
+      int tr_ = ra; ra = rb; rb = tr_;                     \
+      ha = true; hb = false;                               \
+    }
+    CASTER_CMOVE(h0, k0, r0, h1, k1, r1)
+    CASTER_CMOVE(h2, k2, r2, h3, k3, r3)
+    CASTER_CMOVE(h0, k0, r0, h2, k2, r2)
+    CASTER_CMOVE(h1, k1, r1, h3, k3, r3)
+    CASTER_CMOVE(h1, k1, r1, h2, k2, r2)
+#undef CASTER_CMOVE
+  }
 #undef CASTER_CSWAP
   bool ok = true;
   if (nh > 3) ok &= stack_push(st, lane, r3, k3);
@@ -518,6 +536,9 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 //              of its path.
 #ifndef CASTER_SPECULATE
 #define CASTER_SPECULATE 1
+#endif
+#ifndef CASTER_ANY_UNSORTED
+#define CASTER_ANY_UNSORTED 1
 #endif
 #ifndef CASTER_TRACE_WAVES
 #define CASTER_TRACE_WAVES 5
@@ -663,7 +684,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
         CASTER_WS(0, 1);
         CASTER_WS(1, n_inner);
-        if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow, s_top, n_top);
+        if (cur >= 0) cur = node_step<!ANY || !CASTER_ANY_UNSORTED>(S, cur, o, inv, hit.t, st, lane, overflow, s_top, n_top);
       } else if (pend != kRefEmpty) {
         CASTER_WS(2, 1);
         CASTER_WS(3, n_leaf);
@@ -693,7 +714,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       if (n_inner + n_leaf == 0) break;
       if (more && n_free >= kRefillIdle) break;
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
-        if (cur >= 0) cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow, s_top, n_top);
+        if (cur >= 0) cur = node_step<!ANY || !CASTER_ANY_UNSORTED>(S, cur, o, inv, hit.t, st, lane, overflow, s_top, n_top);
       } else if (cur < 0 && cur != kRefEmpty) {
         int i = ~cur;
         float t, b1, b2;
@@ -730,8 +751,9 @@ struct Isect {
 // sphere.h:69-88, line.h:74-84.
 __device__ inline void load_isect(const DevScene& S, V3 o, V3 d, const Hit& h, Isect& is) {
   const float4* sh = S.shade + (size_t)h.prim * kShadeF4;
-  const float4* ir = S.isect + (size_t)h.prim * kIsectF4;
-  uint32_t type = __float_as_uint(ir[2].w) & kPrimTypeMask;
+  // the primitive type sits in the shading record too, so that a shaded hit
+  // touches one 128-byte line and not a second one in the intersection records
+  uint32_t type = __float_as_uint(sh[7].x) & kPrimTypeMask;
   float4 ids = sh[6];
   is.mat = __float_as_int(ids.x);
   is.light = __float_as_int(ids.y);
@@ -1464,7 +1486,7 @@ __global__ __launch_bounds__(kWave) void k_probe_resolve(LaunchCtx L, RayQueue q
     V3 y = v3(0, 0, 0);
     if (found) {
       int light = __float_as_int(S.shade[(size_t)h.prim * kShadeF4 + 6].y);
-      uint32_t type = __float_as_uint(S.isect[(size_t)h.prim * kIsectF4 + 2].w) & kPrimTypeMask;
+      uint32_t type = __float_as_uint(S.shade[(size_t)h.prim * kShadeF4 + 7].x) & kPrimTypeMask;
       if (type == 0u && light != -1) {
         LightRec l;
         load_light(S, light, l);
@@ -1757,7 +1779,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
                   bool found = traverse<false>(S, pos, mo, S.epsilon, INFINITY, lh, st, &L.stats->stack_overflow);
                   if (found) {
                     int light = __float_as_int(S.shade[(size_t)lh.prim * kShadeF4 + 6].y);
-                    uint32_t type = __float_as_uint(S.isect[(size_t)lh.prim * kIsectF4 + 2].w) & kPrimTypeMask;
+                    uint32_t type = __float_as_uint(S.shade[(size_t)lh.prim * kShadeF4 + 7].x) & kPrimTypeMask;
                     if (type == 0u && light != -1) {
                       load_light(S, light, l);
                       const float4* sh = S.shade + (size_t)lh.prim * kShadeF4;

@@ -183,6 +183,7 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
       sh[1] = mk4(p.p1, p.w1);
     }
     sh[6] = make_float4(as_float(p.mat), as_float(p.light), as_float(p.med_in), as_float(p.med_out));
+    sh[7] = make_float4(as_float((uint32_t)p.type & kPrimTypeMask), 0, 0, 0);
   }
   A.lights.resize(sc.lights.size() * kLightF4);
   for (size_t i = 0; i < sc.lights.size(); ++i) {
