@@ -62,6 +62,7 @@ EXPORTS = [
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
     "caster_film_add_device", "caster_primary_ids", "caster_get_stats", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
+    "caster_write_image", "caster_save_image",
 ]
 
 
@@ -108,6 +109,8 @@ def lib():
         L.caster_read_film.argtypes = [vp, fp, C.c_int]
         L.caster_read_film_device.argtypes = [vp, vp, C.c_int]
         L.caster_film_add_device.argtypes = [vp, vp, C.c_uint32]
+        L.caster_write_image.argtypes = [C.c_char_p, C.c_int, C.c_int, fp]
+        L.caster_save_image.argtypes = [vp, C.c_char_p, C.c_int]
         L.caster_primary_ids.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32)]
         L.caster_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.caster_reset_stats.argtypes = [vp]
@@ -187,6 +190,10 @@ class Renderer:
     def film_add_device(self, device_ptr, n_iters):
         _check(lib().caster_film_add_device(self._h, C.c_void_p(device_ptr), n_iters))
 
+    def save_image(self, path, mode=-1):
+        """Writes the film as .png / .exr / .pfm (the reference's SaveImage, CudaRender.cpp:84-90)."""
+        _check(lib().caster_save_image(self._h, os.fspath(path).encode(), mode))
+
     def primary_ids(self, it=1):
         ids = np.empty((self.height, self.width), np.int32)
         _check(lib().caster_primary_ids(self._h, it, ids.ctypes.data_as(C.POINTER(C.c_int32))))
@@ -223,6 +230,15 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+def write_image(path, image):
+    """Writes an (H, W, 3) float32 array, row 0 = bottom scanline, as .png / .exr / .pfm."""
+    a = np.ascontiguousarray(image, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise CasterError(1, "write_image: expected an (H, W, 3) array")
+    _check(lib().caster_write_image(os.fspath(path).encode(), a.shape[1], a.shape[0],
+                                    a.ctypes.data_as(C.POINTER(C.c_float))))
 
 
 # ---- the reference's free-function boundary (pathtracer.h:8-10) ---------------
@@ -306,6 +322,4 @@ class CudaRender:
 
     def SaveImage(self, path):
         """Writes the last image as an 8-bit PNG, top row first (imageio.cpp:62-79)."""
-        from PIL import Image
-        a = (np.clip(self.image[::-1], 0.0, 1.0) * 255.0).astype(np.uint8)
-        Image.fromarray(a).save(path)
+        write_image(path, self.image)

@@ -717,6 +717,26 @@ int caster_read_film(caster_renderer* r, float* rgb, int mode) {
   return CASTER_OK;
 }
 
+int caster_write_image(const char* path, int width, int height, const float* rgb) {
+  if (!path || !rgb || width <= 0 || height <= 0) return fail(CASTER_ERR_ARG, "caster_write_image: bad argument");
+  std::string err;
+  if (!write_image(path, width, height, rgb, err)) return fail(CASTER_ERR_ARG, err);
+  return CASTER_OK;
+}
+
+int caster_save_image(caster_renderer* r, const char* path, int mode) {
+  if (!r || !path || mode < -1 || mode > 2) return fail(CASTER_ERR_ARG, "caster_save_image: bad argument");
+  if (mode < 0) {
+    size_t n = strlen(path);
+    bool png = n >= 4 && (path[n - 3] == 'p' || path[n - 3] == 'P') && (path[n - 2] == 'n' || path[n - 2] == 'N');
+    mode = png ? 1 : 0;
+  }
+  std::vector<float> host((size_t)r->S.width * r->S.height * 3);
+  int rc = caster_read_film(r, host.data(), mode);
+  if (rc) return rc;
+  return caster_write_image(path, r->S.width, r->S.height, host.data());
+}
+
 __global__ void k_film_add(float* acc, const float* add, uint32_t n) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc[i] += add[i];
 }

@@ -5,6 +5,7 @@
 // tagged union.
 #pragma once
 #include <stdint.h>
+#include <cstdint>
 #include <string>
 #include <vector>
 #include "../fpspec.h"
@@ -152,5 +153,8 @@ struct RawMesh {
 bool load_mesh_file(const std::string& path, RawMesh& out, std::string& err);
 bool load_texture_file(const std::string& path, Texture& out, std::string& err);
 bool load_envmap_file(const std::string& path, Infinite& out, std::string& err);
+// image_out.cpp: writes W*H*3 floats (row 0 = bottom scanline) as .png (8-bit, clamped), .exr (half B,G,R) or .pfm
+bool write_image(const std::string& path, int w, int h, const float* rgb, std::string& err);
+uint16_t float_to_half(float f);
 
 }  // namespace caster

@@ -99,6 +99,17 @@ int caster_read_film(caster_renderer* r, float* rgb, int mode);
    output` is a device pointer too); used to hand the film to RCCL. */
 int caster_read_film_device(caster_renderer* r, float* rgb_device, int mode);
 
+/* Replaces ImageIO::SavePng / SaveExr (imageio.cpp:62-79, 105-163) as called by
+   CudaRender::SaveImage (CudaRender.cpp:84-90).  The format follows the
+   extension: .png = 8-bit RGB, top row first, unsigned(clamp(v,0,1)*255) as
+   SavePng; .exr = half-float B,G,R scanlines, top row first; .pfm = raw float32,
+   bottom row first.  caster_write_image writes caller-owned host pixels (W*H*3
+   floats, row 0 = bottom scanline); caster_save_image reads the film first,
+   with `mode` as in caster_read_film or -1 for the format's natural choice
+   (png: tonemapped, exr/pfm: linear mean). */
+int caster_write_image(const char* path, int width, int height, const float* rgb);
+int caster_save_image(caster_renderer* r, const char* path, int mode);
+
 /* Adds `n_iters` to the iteration count and `sum_device` (W*H*3 floats on this
    renderer's device) to the film: merges a film reduced from other GPUs. */
 int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t n_iters);

@@ -132,3 +132,63 @@ def test_sharding_plans(caster):
     assert sh.row_band(45, 1, 2) == (24, 45)
     with pytest.raises(ValueError):
         sh.spp_blocks(1, 4, 0, 0, 1)
+
+
+def _read_exr_half_bgr(path):
+    """Minimal reader for the uncompressed scanline EXR files the library writes."""
+    import struct
+    b = open(path, "rb").read()
+    assert struct.unpack_from("<ii", b, 0) == (20000630, 2)
+    p = 8
+    attrs = {}
+    while b[p] != 0:
+        e = b.index(b"\0", p); name = b[p:e].decode(); p = e + 1
+        e = b.index(b"\0", p); typ = b[p:e].decode(); p = e + 1
+        size = struct.unpack_from("<i", b, p)[0]; p += 4
+        attrs[name] = (typ, b[p:p + size]); p += size
+    p += 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    chans = attrs["channels"][1]
+    names = []
+    q = 0
+    while chans[q] != 0:
+        e = chans.index(b"\0", q); names.append(chans[q:e].decode()); q = e + 1
+        assert struct.unpack_from("<i", chans, q)[0] == 1   # HALF
+        q += 16
+    assert names == ["B", "G", "R"]
+    offs = struct.unpack_from("<%dQ" % h, b, p)
+    img = np.zeros((h, w, 3), np.float16)
+    for y in range(h):
+        yy, n = struct.unpack_from("<ii", b, offs[y])
+        assert yy == y and n == w * 6
+        line = np.frombuffer(b, np.float16, w * 3, offs[y] + 8).reshape(3, w)
+        img[y, :, 2], img[y, :, 1], img[y, :, 0] = line[0], line[1], line[2]
+    return img
+
+
+def test_image_writers(caster, tmp_path):
+    """PNG as the reference's SavePng (flip, clamp, truncate), EXR as half B,G,R, PFM raw."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    img = (rng.random((37, 53, 3), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)
+    img[0, 0] = [np.nan, np.inf, -np.inf]
+    img[1, 1] = [65504.0, 65520.0, 1e-8]
+    img[2, 2] = [6.1e-5, 5.96e-8, 2.98e-8]
+    caster.write_image(tmp_path / "a.png", img)
+    got = np.asarray(Image.open(tmp_path / "a.png"))
+    clean = np.where(np.isnan(img), 0, img)
+    want = (np.clip(clean[::-1], 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+    np.testing.assert_array_equal(got, want)
+    caster.write_image(tmp_path / "a.pfm", img)
+    raw = open(tmp_path / "a.pfm", "rb").read()
+    head = b"PF\n53 37\n-1.0\n"
+    assert raw.startswith(head)
+    np.testing.assert_array_equal(np.frombuffer(raw[len(head):], np.float32).reshape(37, 53, 3), img)
+    caster.write_image(tmp_path / "a.exr", img)
+    exr = _read_exr_half_bgr(tmp_path / "a.exr")
+    with np.errstate(over="ignore"):
+        np.testing.assert_array_equal(exr.view(np.uint16), img[::-1].astype(np.float16).view(np.uint16))
+    with pytest.raises(caster.CasterError):
+        caster.write_image(tmp_path / "a.bmp", img)

@@ -163,3 +163,20 @@ def test_full_size_properties(caster, tmp_path):
     r2.render(1, 2, True)
     np.testing.assert_array_equal(r2.read_film(2), a)
     r2.close()
+
+
+def test_save_image_matches_film(caster, tmp_path):
+    """caster_save_image = read the film + the writer: PNG holds the tonemapped mean, PFM the linear mean."""
+    from PIL import Image
+    sc = caster.Scene(os.path.join(GOLD, "scenes", "cornell_pt", "scene.json"))
+    r = caster.Renderer(sc, 0, 4)
+    r.render(1, 4, True)
+    r.save_image(tmp_path / "f.png")
+    r.save_image(tmp_path / "f.pfm")
+    tone, mean = r.read_film(1), r.read_film(0)
+    r.close()
+    want = (np.clip(tone[::-1], 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "f.png")), want)
+    raw = open(tmp_path / "f.pfm", "rb").read()
+    head = ("PF\n%d %d\n-1.0\n" % (sc.width, sc.height)).encode()
+    np.testing.assert_array_equal(np.frombuffer(raw[len(head):], np.float32).reshape(mean.shape), mean)
