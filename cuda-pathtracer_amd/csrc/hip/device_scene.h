@@ -16,6 +16,8 @@
 //           once per accepted hit by the shade stage
 //   lights  6 x float4 per emissive triangle
 //   mats    6 x float4 per material
+//   media   5 x float4 per medium: grid size | g, sigmaS | type, sigmaT |
+//           1/max density, p0 | offset into `density`, p1 | iteration cap
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,7 +29,7 @@ constexpr int kIsectF4 = 3;
 constexpr int kShadeF4 = 8;
 constexpr int kLightF4 = 6;
 constexpr int kMatF4 = 6;
-constexpr int kMediumF4 = 3;
+constexpr int kMediumF4 = 5;
 
 constexpr int kRefEmpty = (int)0x80000000;  // child reference of an empty subtree
 
@@ -56,6 +58,8 @@ struct DevScene {
   const float4* lights;
   const float4* mats;
   const float4* media;
+  const float* density;  // density grids of the heterogeneous media, back to back
+  int has_hetero;        // some medium is a density grid (its transmittance draws random numbers)
   const float* light_cdf;
   const uint32_t* tex_pool;   // packed rgba8 texels of every texture
   const int* tex_info;        // per texture: offset, width, height

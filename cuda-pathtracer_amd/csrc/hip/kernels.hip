@@ -1587,16 +1587,66 @@ __global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, S
 
 // ---- volumetric path tracing ------------------------------------------------
 __device__ inline V3 vexp(V3 c) { return v3(fps::exp_(c.x), fps::exp_(c.y), fps::exp_(c.z)); }
-struct MediumRec { V3 sigmaS, sigmaT; float g; };
+struct MediumRec { V3 sigmaS, sigmaT; float g; int type; float invMax; };
 __device__ inline void load_medium(const DevScene& S, int idx, MediumRec& m) {
   const float4* r = S.media + (size_t)idx * kMediumF4;
-  float4 a = r[0];
-  m.g = a.w; m.sigmaS = v3(r[1]); m.sigmaT = v3(r[2]);
+  float4 a = r[0], b = r[1], c = r[2];
+  m.g = a.w; m.sigmaS = v3(b); m.type = __float_as_int(b.w); m.sigmaT = v3(c); m.invMax = c.w;
 }
-__device__ inline V3 medium_tr(const DevScene& S, int medium, float tmax) {  // medium.h:13-16
+// Density grid of a heterogeneous medium (medium.h:41-49).
+struct GridRec { int nx, ny, nz, off, iterMax; V3 p0, p1; };
+__device__ inline void load_grid(const DevScene& S, int idx, GridRec& g) {
+  const float4* r = S.media + (size_t)idx * kMediumF4;
+  float4 a = r[0], d = r[3], e = r[4];
+  g.nx = __float_as_int(a.x); g.ny = __float_as_int(a.y); g.nz = __float_as_int(a.z);
+  g.p0 = v3(d); g.off = __float_as_int(d.w); g.p1 = v3(e); g.iterMax = __float_as_int(e.w);
+}
+__device__ inline float het_cell(const DevScene& S, const GridRec& g, V3 p) {  // medium.h:124-129
+  int x = fps::f2i_(p.x), y = fps::f2i_(p.y), z = fps::f2i_(p.z);
+  if (x < 0 || x > g.nx - 1 || y < 0 || y > g.ny - 1 || z < 0 || z > g.nz - 1) return 0.f;
+  return S.density[(size_t)g.off + (size_t)z * g.ny * g.nx + (size_t)y * g.nx + x];
+}
+__device__ inline float lerp_(float a, float b, float t) { return a + t * (b - a); }
+__device__ inline float het_density(const DevScene& S, const GridRec& g, V3 p) {  // medium.h:111-122
+  V3 ps = v3(p.x * g.nx - .5f, p.y * g.ny - .5f, p.z * g.nz - .5f);
+  V3 psi = v3(floorf(ps.x), floorf(ps.y), floorf(ps.z));
+  V3 delta = ps - psi;
+  float d00 = lerp_(het_cell(S, g, psi), het_cell(S, g, psi + v3(1, 0, 0)), delta.x);
+  float d10 = lerp_(het_cell(S, g, psi + v3(0, 1, 0)), het_cell(S, g, psi + v3(1, 1, 0)), delta.x);
+  float d01 = lerp_(het_cell(S, g, psi + v3(0, 0, 1)), het_cell(S, g, psi + v3(1, 0, 1)), delta.x);
+  float d11 = lerp_(het_cell(S, g, psi + v3(0, 1, 1)), het_cell(S, g, psi + v3(1, 1, 1)), delta.x);
+  float d0 = lerp_(d00, d10, delta.y);
+  float d1 = lerp_(d01, d11, delta.y);
+  return lerp_(d0, d1, delta.z);
+}
+// Medium transmittance over [0, tmax] of the ray (o, d): Homogeneous::Tr
+// (medium.h:13-16) or ratio tracking through the density grid (medium.h:53-79),
+// which draws random numbers.
+__device__ V3 medium_tr(const DevScene& S, int medium, V3 o, V3 d, float tmax, uint32_t& rng) {
   MediumRec m;
   load_medium(S, medium, m);
-  return vexp(m.sigmaT * (-tmax));
+  if (m.type == 0) return vexp(m.sigmaT * (-tmax));
+  GridRec g;
+  load_grid(S, medium, g);
+  float sigma = dot(m.sigmaT, v3(0.212671f, 0.715160f, 0.072169f));
+  V3 ext = g.p1 - g.p0;
+  float tr = 1.f;
+  float dist = 0.f;
+  int iter = g.iterMax;
+  while (true) {
+    dist += -fps::log_(rng_uniform(rng)) * m.invMax / sigma;
+    if (dist >= tmax) break;
+    V3 p = o + d * dist;
+    p = (p - g.p0) / ext;
+    tr *= 1.f - het_density(S, g, p) * m.invMax;
+    if (tr < 0.1f) {
+      float q = 1.f - tr;
+      if (rng_uniform(rng) < q) return v3(0.f, 0.f, 0.f);
+      tr /= (1.f - q);
+    }
+    if (--iter == 0) break;
+  }
+  return v3(tr, tr, tr);
 }
 
 constexpr int kMaxCrossings = 1024;
@@ -1604,7 +1654,7 @@ constexpr int kMaxCrossings = 1024;
 // Tr() (pathtracer.cu:307-331): transmittance along a shadow ray, marching
 // through index-matched boundaries; an opaque hit gives zero.
 __device__ V3 transmittance(const DevScene& S, V3 o, V3 d, float tmin, float tmax, int medium, Stack& st,
-                            Stats* stats, uint32_t& segs) {
+                            Stats* stats, uint32_t& segs, uint32_t& rng) {
   V3 tr = v3(1, 1, 1);
   float remaining = tmax;
   float seg_tmax = tmax;
@@ -1621,7 +1671,7 @@ __device__ V3 transmittance(const DevScene& S, V3 o, V3 d, float tmin, float tma
       if (mat != -1) return v3(0, 0, 0);
     }
     float ray_tmax = found ? h.t : seg_tmax;
-    if (medium != -1) tr = tr * medium_tr(S, medium, ray_tmax);
+    if (medium != -1) tr = tr * medium_tr(S, medium, o, d, ray_tmax, rng);
     if (!found) break;
     int m = dot(d, n) > 0 ? med_out : med_in;
     remaining -= ray_tmax;
@@ -1682,22 +1732,46 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
           bool sampledMedium = false;
           MediumRec med;
           if (rmed != -1) {
-            // Homogeneous::Sample (medium.h:18-38)
             load_medium(S, rmed, med);
-            int channel = fps::f2i_(rng_uniform(rng) * 3);
-            channel = channel == 3 ? 2 : channel;
-            float sT = channel == 0 ? med.sigmaT.x : (channel == 1 ? med.sigmaT.y : med.sigmaT.z);
-            float dist = -fps::log_(1 - rng_uniform(rng)) / sT;
-            dist = dist < rtmax ? dist : rtmax;
-            sampledMedium = dist < rtmax;
-            if (sampledMedium) sampledDist = dist;
-            V3 Tr = vexp(med.sigmaT * -dist);
-            V3 density = sampledMedium ? (med.sigmaT * Tr) : Tr;
-            float pdf = 0;
-            pdf += density.x; pdf += density.y; pdf += density.z;
-            pdf /= 3.f;
-            if (pdf == 0) pdf = 1;
-            beta = beta * (sampledMedium ? (Tr * med.sigmaS / pdf) : (Tr / pdf));
+            if (med.type == 0) {
+              // Homogeneous::Sample (medium.h:18-38)
+              int channel = fps::f2i_(rng_uniform(rng) * 3);
+              channel = channel == 3 ? 2 : channel;
+              float sT = channel == 0 ? med.sigmaT.x : (channel == 1 ? med.sigmaT.y : med.sigmaT.z);
+              float dist = -fps::log_(1 - rng_uniform(rng)) / sT;
+              dist = dist < rtmax ? dist : rtmax;
+              sampledMedium = dist < rtmax;
+              if (sampledMedium) sampledDist = dist;
+              V3 Tr = vexp(med.sigmaT * -dist);
+              V3 density = sampledMedium ? (med.sigmaT * Tr) : Tr;
+              float pdf = 0;
+              pdf += density.x; pdf += density.y; pdf += density.z;
+              pdf /= 3.f;
+              if (pdf == 0) pdf = 1;
+              beta = beta * (sampledMedium ? (Tr * med.sigmaS / pdf) : (Tr / pdf));
+            } else {
+              // Heterogeneous::Sample (medium.h:81-109): delta tracking
+              GridRec g;
+              load_grid(S, rmed, g);
+              float sigma = dot(med.sigmaT, v3(0.212671f, 0.715160f, 0.072169f));
+              V3 ext = g.p1 - g.p0;
+              float dist = 0.f;
+              int iter = g.iterMax;
+              while (true) {
+                dist += -fps::log_(rng_uniform(rng)) * med.invMax / sigma;
+                if (dist >= rtmax) break;
+                V3 p = ro + rd * dist;
+                p = (p - g.p0) / ext;
+                if (het_density(S, g, p) * med.invMax > rng_uniform(rng)) {
+                  sampledDist = dist;
+                  sampledMedium = true;
+                  beta = beta * (med.sigmaS / med.sigmaT);
+                  break;
+                }
+                if (--iter == 0) break;
+              }
+              if (!sampledMedium) beta = beta * v3(1.f, 1.f, 1.f);
+            }
           }
           if (is_black(beta)) {
             alive = false;
@@ -1706,8 +1780,11 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
             V3 radiance, ldir;
             float ltmax, lightPdf, choicePdf;
             sample_one_light(S, rng, samplePos, radiance, ldir, ltmax, lightPdf, choicePdf);
-            V3 tr = is_black(radiance) ? v3(1, 1, 1)
-                                       : transmittance(S, samplePos, ldir, S.epsilon, ltmax, rmed, st, L.stats, stat_tr);
+            // the reference walks Tr() whatever the light sample is (pathtracer.cu:1079); the walk
+            // draws random numbers only inside a density grid, so without one it is skipped
+            V3 tr = (is_black(radiance) && !S.has_hetero)
+                        ? v3(1, 1, 1)
+                        : transmittance(S, samplePos, ldir, S.epsilon, ltmax, rmed, st, L.stats, stat_tr, rng);
             // Medium::Phase / SamplePhase (medium.h:146-186)
             float phase;
             if (med.g == 0) phase = ONE_OVER_FOUR_PI;
@@ -1742,7 +1819,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
             bool emitter = (bounces == 0 || specular) && is.light != -1;
             if (emitter) {
               V3 tr = v3(1.f, 1.f, 1.f);
-              if (rmed != -1) tr = vexp(med.sigmaT * (-rtmax));
+              if (rmed != -1) tr = medium_tr(S, rmed, ro, rd, rtmax, rng);
               load_light(S, is.light, l);
               V3 le = dot(nor, -rd) > 0.f ? l.radiance : v3(0, 0, 0);
               Li = Li + tr * beta * le;
@@ -1764,7 +1841,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
                   V3 fr;
                   float samplePdf;
                   eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
-                  V3 tr = transmittance(S, pos, ldir, S.epsilon, ltmax, rmed, st, L.stats, stat_tr);
+                  V3 tr = transmittance(S, pos, ldir, S.epsilon, ltmax, rmed, st, L.stats, stat_tr, rng);
                   float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
                   Ld = Ld + weight * tr * fr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
                 }
@@ -1794,7 +1871,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
                         float lPdf = pdfA * lenSquare / (costheta);
                         float weight = power_heuristic(mpdf, lPdf * cp);
                         V3 tr = v3(1.f, 1.f, 1.f);
-                        if (rmed != -1) tr = medium_tr(S, rmed, lh.t);
+                        if (rmed != -1) tr = medium_tr(S, rmed, pos, mo, lh.t, rng);
                         Ld = Ld + weight * tr * mfr * rad2 * fabsf(dot(mo, nor)) / mpdf;
                       }
                     }
@@ -1803,7 +1880,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
                     float cp = S.light_cdf[S.n_lights + 1] - S.light_cdf[S.n_lights];
                     float weight = power_heuristic(mpdf, ONE_OVER_FOUR_PI * cp);
                     V3 tr = v3(1.f, 1.f, 1.f);
-                    if (rmed != -1) tr = medium_tr(S, rmed, INFINITY);
+                    if (rmed != -1) tr = medium_tr(S, rmed, pos, mo, INFINITY, rng);
                     Ld = Ld + weight * tr * mfr * rad2 * fabsf(dot(mo, nor)) / mpdf;
                   }
                 }

@@ -47,6 +47,7 @@ struct HostArrays {
   std::vector<uint32_t> tex_pool;
   std::vector<int> tex_info;
   std::vector<float> env;
+  std::vector<float> density;
 };
 
 static void build_arrays(const Scene& sc, HostArrays& A) {
@@ -215,9 +216,12 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
   for (size_t i = 0; i < sc.media.size(); ++i) {
     const Medium& m = sc.media[i];
     float4* d = &A.media[i * kMediumF4];
-    d[0] = mk4(m.sigmaA, m.g);
+    d[0] = make_float4(as_float(m.nx), as_float(m.ny), as_float(m.nz), m.g);
     d[1] = mk4(m.sigmaS, as_float(m.type));
-    d[2] = mk4(m.sigmaT, 0.f);
+    d[2] = mk4(m.sigmaT, m.invMaxDensity);
+    d[3] = mk4(m.p0, as_float((int)A.density.size()));
+    d[4] = mk4(m.p1, as_float(m.iterMax));
+    A.density.insert(A.density.end(), m.density.begin(), m.density.end());
   }
   for (const Texture& t : sc.textures) {
     A.tex_info.push_back((int)A.tex_pool.size());
@@ -377,6 +381,8 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   if ((rc = dev_upload(r, &S.lights, A.lights))) return rc;
   if ((rc = dev_upload(r, &S.mats, A.mats))) return rc;
   if ((rc = dev_upload(r, &S.media, A.media))) return rc;
+  if ((rc = dev_upload(r, &S.density, A.density))) return rc;
+  S.has_hetero = sc.has_heterogeneous ? 1 : 0;
   if ((rc = dev_upload(r, &S.light_cdf, sc.light_cdf))) return rc;
   if ((rc = dev_upload(r, &S.tex_pool, A.tex_pool))) return rc;
   if ((rc = dev_upload(r, &S.tex_info, A.tex_info))) return rc;

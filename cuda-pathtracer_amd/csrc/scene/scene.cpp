@@ -1,9 +1,10 @@
 // Scene-file loader: same schema, defaults and push order as the reference
 // parser (CUDA-PathTracer/tracer/parsescene.cpp:46-617), mesh processing as
 // mesh.cpp:29-112, camera as Camera.h:31-43,128-134, light distribution as
-// scene.h:48-81.  Out-of-scope keys (bssrdf materials, heterogeneous media,
-// the lt/bdpt/mlt/sppm/ir integrators) are rejected with an error instead of
+// scene.h:48-81.  Out-of-scope keys (bssrdf materials, the lt/bdpt/mlt/sppm/ir
+// integrators) are rejected with an error instead of
 // being silently mis-rendered.
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -212,7 +213,6 @@ bool load_impl(const char* filename, Scene& scene, std::string& err) {
     for (auto& it : s.arr) {
       const Value& u = *it;
       std::string type = opts(u, "type", "homogeneous");
-      if (type != "homogeneous") { err = "medium type \"" + type + "\" is not supported (homogeneous only)"; return false; }
       f3 sa = opt3(u, "sigmaA", mk3(1, 1, 1)), sS = opt3(u, "sigmaS", mk3(1, 1, 1));
       float sc = optf(u, "scale", 1.f);
       sa = sa * sc; sS = sS * sc;
@@ -220,6 +220,34 @@ bool load_impl(const char* filename, Scene& scene, std::string& err) {
       m.type = MED_HOMOGENEOUS;
       m.g = optf(u, "g", 0.f);
       m.sigmaA = sa; m.sigmaS = sS; m.sigmaT = sa + sS;
+      if (type != "homogeneous") {  // parsescene.cpp:101-131: anything else is the density grid
+        if (m.sigmaT.x != m.sigmaT.y || m.sigmaT.x != m.sigmaT.z) {
+          err = "sigmaA and sigmaS requires uniform attenuation coefficient";
+          return false;
+        }
+        for (const char* key : {"nx", "ny", "nz", "p0", "p1", "density"})
+          if (!u.HasMember(key)) { err = std::string("heterogeneous medium needs \"") + key + "\""; return false; }
+        m.type = MED_HETEROGENEOUS;
+        m.nx = u["nx"].GetInt(); m.ny = u["ny"].GetInt(); m.nz = u["nz"].GetInt();
+        if (m.nx <= 0 || m.ny <= 0 || m.nz <= 0 || (long long)m.nx * m.ny * m.nz > (1ll << 30)) {
+          err = "heterogeneous medium: bad grid size";
+          return false;
+        }
+        m.p0 = opt3(u, "p0", mk3(0, 0, 0)); m.p1 = opt3(u, "p1", mk3(1, 1, 1));
+        m.iterMax = u.HasMember("iterMax") ? u["iterMax"].GetInt() : 1000;
+        // ReadDensityFromFile (medium.h:189-197): whitespace-separated decimal floats
+        std::string file = base + u["density"].GetString();
+        FILE* fp = fopen(file.c_str(), "r");
+        if (!fp) { err = "cannot open density file " + file; return false; }
+        m.density.resize((size_t)m.nx * m.ny * m.nz);
+        for (float& v : m.density)
+          if (fscanf(fp, "%f", &v) != 1) { fclose(fp); err = "density file " + file + " is too short"; return false; }
+        fclose(fp);
+        float mx = 0.f;
+        for (float v : m.density) if (v > mx) mx = v;
+        m.invMaxDensity = 1.f / mx;
+        scene.has_heterogeneous = true;
+      }
       scene.media.push_back(m);
       medium_name.push_back(u["name"].GetString());
     }

@@ -86,10 +86,16 @@ struct Material {  // material.h:15-23
 
 struct Texture { int w = 0, h = 0; std::vector<uint8_t> rgba; };
 
-struct Medium {  // medium.h:7-10,136-139 (homogeneous only)
+struct Medium {  // medium.h:7-10, 41-49, 136-139
   int type;
   float g;
   f3 sigmaA, sigmaS, sigmaT;
+  // heterogeneous only: density grid over the box [p0, p1], z-major (medium.h:124-128)
+  int nx = 0, ny = 0, nz = 0;
+  std::vector<float> density;
+  float invMaxDensity = 0.f;
+  f3 p0{0, 0, 0}, p1{0, 0, 0};
+  int iterMax = 1000;
 };
 
 struct Light {  // area.h:5-10; the triangle is prims[prim]
@@ -127,6 +133,7 @@ struct Scene {
   std::vector<Material> materials;
   std::vector<Texture> textures;
   std::vector<Medium> media;
+  bool has_heterogeneous = false;  // some medium is a density grid: transmittance then consumes random numbers
   std::vector<Prim> prims;   // canonical (BVH leaf) order; hit ids index this
   std::vector<Node> nodes;
   BBox root_box;

@@ -450,6 +450,78 @@ inline V3 HomogeneousSample(const caster::Medium& m, const Ray& ray, Rng& rng, f
   if (pdf == 0) pdf = 1;
   return sampled ? (Tr * v3(m.sigmaS) / pdf) : (Tr / pdf);
 }
+// medium.h:116-129: grid lookup, zero outside; float -> int truncates
+inline float HetCell(const caster::Medium& m, V3 p) {
+  int x = fps::f2i_(p.x), y = fps::f2i_(p.y), z = fps::f2i_(p.z);
+  if (x < 0 || x > m.nx - 1 || y < 0 || y > m.ny - 1 || z < 0 || z > m.nz - 1) return 0.f;
+  return m.density[(size_t)z * m.ny * m.nx + (size_t)y * m.nx + x];
+}
+inline float Lerp(float a, float b, float t) { return a + t * (b - a); }  // cutil_math.h lerp
+// medium.h:103-114: trilinear density at p in [0,1]^3 of the grid's box
+inline float HetDensity(const caster::Medium& m, V3 p) {
+  V3 ps = v3(p.x * m.nx - .5f, p.y * m.ny - .5f, p.z * m.nz - .5f);
+  V3 psi = v3(floorf(ps.x), floorf(ps.y), floorf(ps.z));
+  V3 delta = ps - psi;
+  float d00 = Lerp(HetCell(m, psi), HetCell(m, psi + v3(1, 0, 0)), delta.x);
+  float d10 = Lerp(HetCell(m, psi + v3(0, 1, 0)), HetCell(m, psi + v3(1, 1, 0)), delta.x);
+  float d01 = Lerp(HetCell(m, psi + v3(0, 0, 1)), HetCell(m, psi + v3(1, 0, 1)), delta.x);
+  float d11 = Lerp(HetCell(m, psi + v3(0, 1, 1)), HetCell(m, psi + v3(1, 1, 1)), delta.x);
+  float d0 = Lerp(d00, d10, delta.y);
+  float d1 = Lerp(d01, d11, delta.y);
+  return Lerp(d0, d1, delta.z);
+}
+// medium.h:53-79: ratio tracking
+inline V3 HeterogeneousTr(const caster::Medium& m, const Ray& ray, Rng& rng) {
+  float sigma = dot(v3(m.sigmaT), v3(0.212671f, 0.715160f, 0.072169f));
+  V3 d = v3(m.p1) - v3(m.p0);
+  float tr = 1.f;
+  float dist = 0.f;
+  int iter = m.iterMax;
+  while (true) {
+    dist += -fps::log_(rng.uniform()) * m.invMaxDensity / sigma;
+    if (dist >= ray.tmax) break;
+    V3 p = ray.at(dist);
+    p = (p - v3(m.p0)) / d;
+    tr *= 1.f - HetDensity(m, p) * m.invMaxDensity;
+    if (tr < 0.1f) {
+      float q = 1.f - tr;
+      if (rng.uniform() < q) return v3(0.f, 0.f, 0.f);
+      tr /= (1.f - q);
+    }
+    if (--iter == 0) break;
+  }
+  return v3(tr, tr, tr);
+}
+// medium.h:81-109: delta tracking
+inline V3 HeterogeneousSample(const caster::Medium& m, const Ray& ray, Rng& rng, float& t, bool& sampled) {
+  float sigma = dot(v3(m.sigmaT), v3(0.212671f, 0.715160f, 0.072169f));
+  V3 d = v3(m.p1) - v3(m.p0);
+  float dist = 0.f;
+  int iter = m.iterMax;
+  while (true) {
+    dist += -fps::log_(rng.uniform()) * m.invMaxDensity / sigma;
+    if (dist >= ray.tmax) break;
+    V3 p = ray.at(dist);
+    p = (p - v3(m.p0)) / d;
+    if (HetDensity(m, p) * m.invMaxDensity > rng.uniform()) {
+      t = dist;
+      sampled = true;
+      return v3(m.sigmaS) / v3(m.sigmaT);
+    }
+    if (--iter == 0) break;
+  }
+  t = dist;
+  sampled = false;
+  return v3(1.f, 1.f, 1.f);
+}
+// the type switch of pathtracer.cu:317-320, 1056-1059
+inline V3 MediumTr(const caster::Medium& m, const Ray& ray, Rng& rng) {
+  return m.type == caster::MED_HOMOGENEOUS ? HomogeneousTr(m, ray) : HeterogeneousTr(m, ray, rng);
+}
+inline V3 MediumSample(const caster::Medium& m, const Ray& ray, Rng& rng, float& t, bool& sampled) {
+  return m.type == caster::MED_HOMOGENEOUS ? HomogeneousSample(m, ray, rng, t, sampled)
+                                           : HeterogeneousSample(m, ray, rng, t, sampled);
+}
 // medium.h:146-172
 inline void SamplePhase(const caster::Medium& m, V2 u, V3& dir, float& phase, float& pdf) {
   float g = m.g;
@@ -487,14 +559,14 @@ inline int MediumBySide(float side, const Isect& is) {  // pathtracer.cu:324-325
 }
 
 // pathtracer.cu:307-331
-V3 Tr(const Ctx& cx, Ray& ray, Counters& k) {
+V3 Tr(const Ctx& cx, Ray& ray, Rng& rng, Counters& k) {
   V3 tr = v3(1, 1, 1);
   float tmax = ray.tmax;
   for (int guard = 0; guard < kMaxCrossings; ++guard) {
     Isect isect;
     bool invisible = Intersect(cx, ray, &isect, k, RK_TR);
     if (invisible && isect.matIdx != -1) return v3(0, 0, 0);
-    if (ray.medium != -1) tr *= HomogeneousTr(cx.scene.media[ray.medium], ray);
+    if (ray.medium != -1) tr *= MediumTr(cx.scene.media[ray.medium], ray, rng);
     if (!invisible) break;
     int m = MediumBySide(dot(ray.dir, isect.n), isect);
     tmax -= ray.tmax;
@@ -1055,7 +1127,7 @@ bool Ao(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& k) {
 // Direct lighting by BSDF sampling (pathtracer.cu:943-983 and 1142-1194);
 // `vol` adds the transmittance factor of the volumetric variant.
 inline V3 BsdfSampledLight(const Ctx& cx, const Material& material, const Ray& r, V3 pos, V3 nor, V2 uv, V3 dpdu,
-                           V3 us, bool vol, Counters& k) {
+                           V3 us, bool vol, Rng& rng, Counters& k) {
   V3 Ld = v3(0, 0, 0);
   V3 out, fr;
   float pdf;
@@ -1078,7 +1150,7 @@ inline V3 BsdfSampledLight(const Ctx& cx, const Material& material, const Ray& r
         float weight = PowerHeuristic(1, pdf, 1, lPdf * choicePdf);
         if (vol) {
           V3 tr = v3(1.f, 1.f, 1.f);
-          if (lightRay.medium != -1) tr = HomogeneousTr(cx.scene.media[lightRay.medium], lightRay);
+          if (lightRay.medium != -1) tr = MediumTr(cx.scene.media[lightRay.medium], lightRay, rng);
           Ld += weight * tr * fr * radiance * fabsf(dot(out, nor)) / pdf;
         } else {
           Ld += weight * fr * radiance * fabsf(dot(out, nor)) / pdf;
@@ -1092,7 +1164,7 @@ inline V3 BsdfSampledLight(const Ctx& cx, const Material& material, const Ray& r
       float weight = PowerHeuristic(1, pdf, 1, lightPdf * choicePdf);
       if (vol) {
         V3 tr = v3(1.f, 1.f, 1.f);
-        if (lightRay.medium != -1) tr = HomogeneousTr(cx.scene.media[lightRay.medium], lightRay);
+        if (lightRay.medium != -1) tr = MediumTr(cx.scene.media[lightRay.medium], lightRay, rng);
         Ld += weight * tr * fr * radiance * fabsf(dot(out, nor)) / pdf;
       } else {
         Ld += weight * fr * radiance * fabsf(dot(out, nor)) / pdf;
@@ -1148,7 +1220,7 @@ bool Path(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& k) 
       }
       V3 us;
       us.x = rng.uniform(); us.y = rng.uniform(); us.z = rng.uniform();
-      Ld += BsdfSampledLight(cx, material, r, pos, nor, uv, dpdu, us, false, k);
+      Ld += BsdfSampledLight(cx, material, r, pos, nor, uv, dpdu, us, false, rng, k);
       Li += beta * Ld;
     }
 
@@ -1198,7 +1270,7 @@ bool Volpath(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& 
 
     float sampledDist = 0.f;
     bool sampledMedium = false;
-    if (r.medium != -1) beta *= HomogeneousSample(cx.scene.media[r.medium], r, rng, sampledDist, sampledMedium);
+    if (r.medium != -1) beta *= MediumSample(cx.scene.media[r.medium], r, rng, sampledDist, sampledMedium);
     if (IsBlack(beta)) break;
     if (sampledMedium) {
       const caster::Medium& med = cx.scene.media[r.medium];
@@ -1210,9 +1282,10 @@ bool Volpath(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& 
       // neither consumes a draw out of order)
       SampleOneLight(cx, rng, samplePos, radiance, shadowRay, lightPdf, choicePdf);
       shadowRay.medium = r.medium;
-      // Tr() draws no random numbers for a homogeneous medium, so skipping it
-      // when the light sample is black changes nothing but the ray count.
-      V3 tr = IsBlack(radiance) ? v3(1, 1, 1) : Tr(cx, shadowRay, k);
+      // The reference calls Tr() whatever the light sample is (pathtracer.cu:1079).
+      // Tr() draws random numbers only inside a density grid, so without one in
+      // the scene a black sample skips the walk; that changes the ray count only.
+      V3 tr = (IsBlack(radiance) && !cx.scene.has_heterogeneous) ? v3(1, 1, 1) : Tr(cx, shadowRay, rng, k);
       float phase, unuse;
       Phase(med, -r.dir, shadowRay.dir, phase, unuse);
       if (!IsBlack(radiance)) Li += tr * beta * phase * radiance / (lightPdf * choicePdf);
@@ -1227,7 +1300,7 @@ bool Volpath(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& 
       if (bounces == 0 || specular) {
         if (isect.lightIdx != -1) {
           V3 tr = v3(1.f, 1.f, 1.f);
-          if (r.medium != -1) tr = HomogeneousTr(cx.scene.media[r.medium], r);
+          if (r.medium != -1) tr = MediumTr(cx.scene.media[r.medium], r, rng);
           Li += tr * beta * AreaLe(cx, isect.lightIdx, nor, -r.dir);
           break;
         }
@@ -1251,13 +1324,13 @@ bool Volpath(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& 
           V3 fr;
           float samplePdf;
           Fr(cx, material, -r.dir, shadowRay.dir, nor, uv, dpdu, fr, samplePdf);
-          V3 tr = Tr(cx, shadowRay, k);
+          V3 tr = Tr(cx, shadowRay, rng, k);
           float weight = PowerHeuristic(1, lightPdf * choicePdf, 1, samplePdf);
           Ld += weight * tr * fr * radiance * fabsf(dot(nor, shadowRay.dir)) / (lightPdf * choicePdf);
         }
         V3 us;
         us.x = rng.uniform(); us.y = rng.uniform(); us.z = rng.uniform();
-        Ld += BsdfSampledLight(cx, material, r, pos, nor, uv, dpdu, us, true, k);
+        Ld += BsdfSampledLight(cx, material, r, pos, nor, uv, dpdu, us, true, rng, k);
         Li += beta * Ld;
       }
       V3 u;

@@ -77,7 +77,9 @@ def test_parser_ao_and_lights(caster, tmp_path):
     ({"camera": {}, "integrator": "bdpt"}, "integrator"),                           # out of scope: rejected
     ({"camera": {}, "scene": [{"mesh": "q.obj", "material": "nope"}]}, "no material named"),  # :384-385
     ({"camera": {}, "scene": [{"cube": True}]}, "format"),                           # :488-491
-    ({"camera": {}, "medium": [{"name": "a", "type": "heterogeneous"}]}, "homogeneous"),
+    ({"camera": {}, "medium": [{"name": "a", "type": "heterogeneous"}]}, "heterogeneous medium needs"),
+    ({"camera": {}, "medium": [{"name": "a", "type": "heterogeneous", "sigmaA": [1, 2, 1], "nx": 1, "ny": 1, "nz": 1,
+                                "p0": [0, 0, 0], "p1": [1, 1, 1], "density": "d.txt"}]}, "uniform attenuation"),
 ])
 def test_parser_errors(caster, tmp_path, doc, needle):
     with pytest.raises(caster.CasterError) as e:

@@ -12,6 +12,7 @@ reference's JSON schema (CUDA-PathTracer/tracer/parsescene.cpp:46-598):
                textured Lambertian ground
   stairs_pt    "staircase2" stand-in: RoughConductor / RoughDielectric /
                Substrate materials, Line railings
+  cornell_smoke  Cornell box with a heterogeneous medium (density grid) in an index-matched box
   cornell_vpt  Cornell box with a homogeneous medium inside an index-matched
                box boundary and a glass sphere, volumetric path tracing
   car_pt       "bmw-m6" stand-in: >= 1 M triangle displaced body, glass
@@ -310,6 +311,26 @@ def scene_cornell_vpt(out, a):
     }
 
 
+def scene_cornell_smoke(out, a):
+    """Cornell box with a plume of smoke: a heterogeneous medium (density grid, delta / ratio
+    tracking) inside an index-matched boundary box, g != 0 so that the Henyey-Greenstein
+    branches of the phase function run too."""
+    s = scene_cornell_vpt(out, a)
+    n = 20
+    z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    u, v, w = (x + 0.5) / n - 0.5, (y + 0.5) / n, (z + 0.5) / n - 0.5
+    r = np.sqrt((u - 0.12 * np.sin(7 * v)) ** 2 + (w - 0.1 * np.cos(5 * v)) ** 2)
+    dens = np.clip(1.0 - r / (0.12 + 0.3 * v), 0, 1) * (0.35 + 0.65 * np.abs(np.sin(9 * u + 4 * v) * np.cos(8 * w)))
+    with open(os.path.join(out, "smoke.txt"), "w") as f:
+        for val in dens.reshape(-1):   # z-major, then y, then x
+            f.write("%.6f\n" % val)
+    s["medium"] = [{"name": "fog", "type": "heterogeneous", "sigmaA": [0.5, 0.5, 0.5], "sigmaS": [5.5, 5.5, 5.5],
+                    "scale": 2.0, "g": 0.4, "nx": n, "ny": n, "nz": n, "p0": [-0.75, 0.25, -0.75],
+                    "p1": [0.75, 1.35, 0.75], "density": "smoke.txt", "iterMax": 200}]
+    s["scene"][4] = {"sphere": True, "center": [0.55, 0.3, 0.7], "radius": 0.3, "material": "glass"}
+    return s
+
+
 def scene_knot_pt(out, a):
     d = a.detail
     nu, nv = max(24, int(600 * d)), max(8, int(128 * d))
@@ -456,6 +477,7 @@ def scene_car_pt(out, a):
 
 SCENES = {
     "cornell_ao": scene_cornell_ao, "cornell_pt": scene_cornell_pt, "cornell_vpt": scene_cornell_vpt,
+    "cornell_smoke": scene_cornell_smoke,
     "knot_pt": scene_knot_pt, "stairs_pt": scene_stairs_pt, "car_pt": scene_car_pt,
 }
 
