@@ -95,6 +95,7 @@ struct PathState {
 constexpr uint32_t kFBounceMask = 0xffffu;       // bounce counter
 constexpr uint32_t kFSpecular = 1u << 16;
 constexpr uint32_t kFPending = 1u << 17;
+constexpr uint32_t kFPendingY = 1u << 18;        // pend_y holds a BSDF-sampled term (else it counts as zero)
 constexpr uint32_t kFMediumShift = 20;           // bits 20..27: medium index + 1
 constexpr uint32_t kFMediumMask = 0xffu << kFMediumShift;
 

@@ -484,6 +484,33 @@ struct LaunchCtx {
   Stats* stats;
 };
 
+// Slot of (iteration k of the batch, pixel slot `local` of one iteration).  The
+// batch is laid out tile by tile: the n_iter wavefronts (8x8 pixels of one
+// iteration each) of a tile follow one another, so that a contiguous part of a
+// queue -- what one XCD's wavefronts consume -- covers a band of the image
+// rather than a few iterations of all of it, and that XCD's L2 sees the
+// geometry of that band.
+#ifndef CASTER_TILE_MAJOR
+#define CASTER_TILE_MAJOR 1
+#endif
+__device__ inline uint32_t batch_slot(const DevScene& S, uint32_t k, uint32_t local, uint32_t n_iter) {
+#if CASTER_TILE_MAJOR
+  return (((local >> 6) * n_iter + k) << 6) | (local & 63u);
+#else
+  return k * (uint32_t)S.slots_per_iter + local;
+#endif
+}
+__device__ inline void batch_slot_split(const DevScene& S, uint32_t slot, uint32_t n_iter, uint32_t& k, uint32_t& local) {
+#if CASTER_TILE_MAJOR
+  uint32_t w = slot >> 6, tile = w / n_iter;
+  k = w - tile * n_iter;
+  local = (tile << 6) | (slot & 63u);
+#else
+  k = slot / (uint32_t)S.slots_per_iter;
+  local = slot - k * (uint32_t)S.slots_per_iter;
+#endif
+}
+
 // Camera samples for iterations [first_iter, first_iter + n_iter): seeds the
 // RNG, draws the four camera numbers (pathtracer.cu:881-890), writes the
 // extension ray and fresh path state.  Queue index == path slot here.
@@ -492,8 +519,8 @@ __global__ __launch_bounds__(kWave) void k_generate(LaunchCtx L, RayQueue q, uin
   const DevScene& S = L.S;
   uint32_t total = (uint32_t)S.slots_per_iter * n_iter;
   for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < total; idx += gridDim.x * kWave) {
-    uint32_t k = idx / (uint32_t)S.slots_per_iter;
-    uint32_t local = idx - k * (uint32_t)S.slots_per_iter;
+    uint32_t k, local;
+    batch_slot_split(S, idx, n_iter, k, local);
     uint32_t px, py;
     bool live = slot_pixel(S, local, px, py) && (int)py >= y0 && (int)py < y1;
     uint32_t iter = first_iter + k;
@@ -1295,9 +1322,9 @@ __device__ inline void wave_rounds(uint32_t count, uint32_t& r0, uint32_t& r1) {
 
 // Adds the two direct-light terms left pending by the previous vertex:
 // Li += beta * (Ld_light + Ld_bsdf)  (pathtracer.cu:984).
-__device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li) {
+__device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li, uint32_t flags) {
   V3 x = v3(P.pend_x[slot]);
-  V3 y = v3(P.pend_y[slot]);
+  V3 y = (flags & kFPendingY) ? v3(P.pend_y[slot]) : v3(0.f, 0.f, 0.f);
   V3 bp = v3(P.beta_prev[slot]);
   V3 Ld = x + y;
   return Li + bp * Ld;
@@ -1347,8 +1374,8 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
       int bounces = (int)(flags & kFBounceMask);
       bool specular = (flags & kFSpecular) != 0;
       if (flags & kFPending) {
-        Li = resolve_pending(P, slot, Li);
-        flags &= ~kFPending;
+        Li = resolve_pending(P, slot, Li, flags);
+        flags &= ~(kFPending | kFPendingY);
       }
       bool alive = true;
       if (h.prim < 0) {
@@ -1425,10 +1452,18 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
               }
 #endif
             }
-            P.pend_x[slot] = f4(x, absdot);
-            P.pend_y[slot] = py;
-            P.beta_prev[slot] = f4(beta, 0.f);
-            flags |= kFPending;
+            // Li += beta * (x + y) is owed once visibility and the probe are known.
+            // Without a probe y counts as zero and is not stored; when x is zero
+            // as well the sum adds beta * 0, which only matters for a non-finite
+            // beta (the sample then turns NaN and is dropped), so a finite beta
+            // stores nothing at all.
+            bool finite_beta = fabsf(beta.x) < INFINITY && fabsf(beta.y) < INFINITY && fabsf(beta.z) < INFINITY;
+            if (want_probe || !is_black(x) || !finite_beta) {
+              P.pend_x[slot] = f4(x, absdot);
+              if (want_probe) P.pend_y[slot] = py;
+              P.beta_prev[slot] = f4(beta, 0.f);
+              flags |= kFPending | (want_probe ? kFPendingY : 0u);
+            }
           }
           // continuation
           V3 u;
@@ -1523,8 +1558,8 @@ __global__ __launch_bounds__(kWave) void k_probe_resolve(LaunchCtx L, RayQueue q
   }
 }
 
-// Probe rays that were never issued leave (fr,pdf) = 0 in pend_y, which reads
-// as a zero contribution; issued ones are always overwritten by k_probe_resolve.
+// A vertex whose probe ray was never issued does not set kFPendingY, so its
+// pend_y is not read; issued ones are always overwritten by k_probe_resolve.
 
 // One vertex of Ao() (pathtracer.cu:841-868).
 __global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
@@ -1568,7 +1603,6 @@ __global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, S
           float cosine = dot(wi, n);
           float v = cosine / pdf;
           P.pend_x[slot] = f4(v3(v, v, v), 0.f);
-          P.pend_y[slot] = make_float4(0, 0, 0, 0);
           P.beta_prev[slot] = f4(v3(1, 1, 1), 0.f);
           flags |= kFPending;
           want_shadow = true;
@@ -1953,11 +1987,11 @@ __global__ void k_finish(LaunchCtx L, float* acc, uint32_t n_iter, int y0, int y
     uint32_t pixel = px + py * (uint32_t)S.width;
     V3 a = v3(acc[3 * pixel], acc[3 * pixel + 1], acc[3 * pixel + 2]);
     for (uint32_t k = 0; k < n_iter; ++k) {
-      uint32_t slot = k * (uint32_t)S.slots_per_iter + local;
+      uint32_t slot = batch_slot(S, k, local, n_iter);
       float4 lf = L.P.li_flags[slot];
       V3 Li = v3(lf);
       uint32_t flags = __float_as_uint(lf.w);
-      if (flags & kFPending) Li = resolve_pending(L.P, (int)slot, Li);
+      if (flags & kFPending) Li = resolve_pending(L.P, (int)slot, Li, flags);
       bool bad = S.integrator == 0 ? has_nan(Li) : (has_nan(Li) || has_inf(Li));
       if (bad) ++invalid;
       else a = a + Li;
