@@ -211,9 +211,9 @@ def main():
             threads = a.cpu_threads or min(os.cpu_count() or 1, 16)
             c = ol.Counts()
             # bounded sample: every 8th block of 8 scanlines of the frame, 1 spp
-            rows = [(y, min(y + 8, scene.height)) for y in range(0, scene.height, 64)]
+            sample_rows = [(y, min(y + 8, scene.height)) for y in range(0, scene.height, 64)]
             t0 = time.perf_counter()
-            for y0, y1 in rows:
+            for y0, y1 in sample_rows:
                 o.render(1, 1, threads, counts=c, rows=(y0, y1))
             tc = time.perf_counter() - t0
             n_cpu = c.samples
@@ -230,31 +230,75 @@ def main():
                 "single_thread_msamples_per_s": c1.samples / tc1 / 1e6,
                 "mrays_per_s": sum(counts["rays"]) / tc / 1e6,
             }
-        # roofline of the dominant kernel, by kernel symbol as rocprofv3 reports it:
-        # k_trace<false> runs the extension and the probe rays, k_trace<true> the shadow rays
-        symbols = {"k_trace<false>": (("extend", 0), ("probe", 2)), "k_trace<true>": (("shadow", 1),)}
-        dom = max(symbols, key=lambda k: sum(kt[c][0] for c, _ in symbols[k]))
-        ms = sum(kt[c][0] for c, _ in symbols[dom])
-        launches = sum(kt[c][1] for c, _ in symbols[dom])
-        roof = {"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "traffic": pmc_traffic_per_launch(dom),
-                "avg_launch_ms": ms / max(launches, 1), "launches": launches}
-        if counts is not None and ms > 0:
+        # Roofline, by kernel symbol as rocprofv3 reports it: k_trace<false> runs the extension and
+        # the probe rays, k_trace<true> the shadow rays, k_shade_* one path vertex per extension ray.
+        # The dominant kernel is the one with the largest total time in the timed region.  With
+        # several streams a launch shares the GPU with the other streams' kernels while it runs, so
+        # `exclusive` repeats the measurement on one stream (same batch size), after the timed region.
+        shade_name = {0: "k_shade_ao", 1: "k_shade_pt", 2: "k_shade_vpt"}[scene.integrator]
+        symbols = {"k_trace<false>": (("extend", 0), ("probe", 2)), "k_trace<true>": (("shadow", 1),),
+                   shade_name: (("shade", None),)}
+
+        def algorithmic_bytes(sym, rays_now):
+            """SURVEY-defined bytes the launches of `sym` had to move for `rays_now` = this rank's ray
+            counts [extension, shadow, probe, transmittance]."""
+            if counts is None:
+                return None
+            if sym == shade_name:
+                # per vertex: ray + hit read (32 + 16 B), path state read + write (2 x 32 B); per accepted
+                # hit: shading fetch 96 B + indices 20 B + material 72 B; per emitted ray: 32 B written
+                vertices = rays_now[0]
+                hit_frac = counts["hits"][0] / max(counts["rays"][0], 1)
+                emitted = max(rays_now[0] - total_samples_rank, 0) + rays_now[1] + rays_now[2]
+                return vertices * (48.0 + 64.0) + vertices * hit_frac * 188.0 + emitted * 32.0
             record = {"extend": 32 + 16, "shadow": 32 + 4, "probe": 32 + 4 + 16}
-            # this rank's rays of those kinds in the timed region x the oracle's bytes per ray of that kind
-            alg = sum(st["rays"][kind] * (algorithmic_bytes_per_ray(counts, kind) + record[c])
-                      for c, kind in symbols[dom])
-            n_rays = sum(st["rays"][kind] for _, kind in symbols[dom])
-            o_rays = sum(counts["rays"][kind] for _, kind in symbols[dom])
-            achieved = alg / (ms * 1e-3) / 1e9
-            roof.update(achieved=achieved, frac=achieved / HBM_PEAK_GBS,
-                        algorithmic_bytes_per_ray=alg / max(n_rays, 1),
-                        algorithmic_bytes_per_launch=alg / max(launches, 1),
-                        rays_per_launch=n_rays / max(launches, 1),
-                        nodes_per_ray=sum(counts["nodes"][kind] for _, kind in symbols[dom]) / max(o_rays, 1),
-                        tris_per_ray=sum(counts["tris"][kind] for _, kind in symbols[dom]) / max(o_rays, 1))
-        else:
-            roof.update(achieved=None, frac=None)
+            return sum(rays_now[kind] * (algorithmic_bytes_per_ray(counts, kind) + record[c]) for c, kind in symbols[sym])
+
+        def roofline_of(sym, times, rays_now):
+            ms = sum(times[c][0] for c, _ in symbols[sym])
+            launches = sum(times[c][1] for c, _ in symbols[sym])
+            alg = algorithmic_bytes(sym, rays_now)
+            r = {"kernel": sym, "total_ms": ms, "launches": launches, "avg_launch_ms": ms / max(launches, 1)}
+            if alg is not None and ms > 0:
+                r.update(achieved=alg / (ms * 1e-3) / 1e9, frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         algorithmic_bytes_per_launch=alg / max(launches, 1))
+            else:
+                r.update(achieved=None, frac=None)
+            return r
+
+        total_samples_rank = st["samples"]
+        per_kernel = [roofline_of(sym, kt, st["rays"]) for sym in symbols]
+        dom = max(per_kernel, key=lambda r: r["total_ms"])
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": pmc_traffic_per_launch(dom["kernel"])}
+        roof.update(dom)
+        if counts is not None:
+            kinds = [kind for _, kind in symbols[dom["kernel"]] if kind is not None] or [0]
+            o_rays = sum(counts["rays"][kind] for kind in kinds)
+            roof.update(nodes_per_ray=sum(counts["nodes"][kind] for kind in kinds) / max(o_rays, 1),
+                        tris_per_ray=sum(counts["tris"][kind] for kind in kinds) / max(o_rays, 1))
+        # one-stream repeat: each launch has the GPU to itself
+        try:
+            r1 = caster.Renderer(scene, dev_index, r.iters_in_flight, 1)
+            if rows != (0, scene.height):
+                r1.set_rows(*rows)
+            n1 = r.iters_in_flight
+            r1.render(1, n1, True)
+            r1.reset_stats()
+            r1.set_profiling(True)
+            t1 = time.perf_counter()
+            r1.render(1 + n1, 2 * n1, False)
+            dt1 = time.perf_counter() - t1
+            st1, kt1 = r1.stats(), r1.kernel_times()
+            r1.close()
+            total_samples_rank = st1["samples"]
+            ex = [roofline_of(sym, kt1, st1["rays"]) for sym in symbols]
+            roof["exclusive"] = {"streams": 1, "msamples_per_s": st1["samples"] / dt1 / 1e6,
+                                 "kernels": [{k: v for k, v in e.items() if k in ("kernel", "avg_launch_ms", "achieved", "frac", "launches")}
+                                             for e in ex]}
+        except caster.CasterError as e:
+            roof["exclusive"] = {"error": str(e)}
+        roof["kernels"] = [{k: v for k, v in e.items() if k in ("kernel", "total_ms", "avg_launch_ms", "achieved", "frac", "launches")}
+                           for e in per_kernel]
         out["roofline"] = roof
         print(json.dumps(out))
     r.close()

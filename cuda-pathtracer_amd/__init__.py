@@ -62,7 +62,7 @@ EXPORTS = [
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
     "caster_film_add_device", "caster_primary_ids", "caster_get_stats", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
-    "caster_write_image", "caster_save_image",
+    "caster_write_image", "caster_save_image", "caster_iters_in_flight",
 ]
 
 
@@ -116,6 +116,7 @@ def lib():
         L.caster_reset_stats.argtypes = [vp]
         L.caster_set_profiling.argtypes = [vp, C.c_int]
         L.caster_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+        L.caster_iters_in_flight.argtypes = [vp]
         L.caster_iterations.argtypes = [vp]
         L.caster_iterations.restype = C.c_uint32
         L.caster_end.argtypes = [vp]
@@ -166,6 +167,7 @@ class Renderer:
         self.width, self.height = scene.width, scene.height
         self.integrator = scene.integrator
         self.device = device
+        self.iters_in_flight = lib().caster_iters_in_flight(self._h)
 
     def set_rows(self, y0, y1):
         _check(lib().caster_set_rows(self._h, y0, y1))

@@ -228,10 +228,16 @@ struct Hit {
 // edge vectors and coordinate maxima precomputed per primitive (the same
 // float operations, done once on the host).  Sphere: sphere.h:24-66.  Line:
 // line.h:33-72.
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, float maxD, float tmin,
+                                     float tmax, float& t, float& ob1, float& ob2, bool& last);
 __device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, float tmax,
                                  float& t, float& ob1, float& ob2, bool& last) {
   const float4* rec = S.isect + (size_t)i * kIsectF4;
-  float4 a = rec[0], b = rec[1], c = rec[2];
+  return prim_test_rec(S, rec[0], rec[1], rec[2], o, d, maxD, tmin, tmax, t, ob1, ob2, last);
+}
+// The same test on a record already in registers.
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, float maxD, float tmin,
+                                     float tmax, float& t, float& ob1, float& ob2, bool& last) {
   uint32_t bits = __float_as_uint(c.w);
   last = (bits & kPrimLastInLeaf) != 0;
   uint32_t type = bits & kPrimTypeMask;
@@ -1181,6 +1187,18 @@ __device__ inline void load_light(const DevScene& S, int idx, LightRec& l) {
   l.area = a.w; l.radiance = v3(b.w, c.w, d.w); l.prim = __float_as_int(e.w);
 }
 
+// Loads whose address is the same for every lane of the wavefront, from tables
+// that no kernel writes (lights, the light distribution): through the constant
+// address space they become scalar loads, which bypass the per-lane vector
+// memory pipeline and return into scalar registers.
+typedef __attribute__((address_space(4))) const v4f_t const_v4f_t;
+typedef __attribute__((address_space(4))) const float const_f32_t;
+__device__ inline float4 uniform_load4(const float4* p) {
+  v4f_t v = *(const_v4f_t*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ inline float uniform_load(const float* p) { return *(const_f32_t*)p; }
+
 // Environment lookup (infinite.h:46-93)
 __device__ inline V3 inf_texel(const DevInfinite& I, int x, int y) {
   int width = I.w, height = I.h;
@@ -1220,21 +1238,21 @@ __device__ inline V3 inf_le(const DevInfinite& I, V3 dir) {
 
 // LookUpLightDistribution (pathtracer.cu:181-190); no matching bin -> last bin.
 __device__ inline int pick_light(const DevScene& S, float u, float& pdf) {
+  // first bin [cdf[i], cdf[i+1]] that holds u (pathtracer.cu:181-190); the last bin when none does
   int n = S.n_cdf;
-  for (int i = 0; i + 1 < n; ++i) {
-    float s = S.light_cdf[i], e = S.light_cdf[i + 1];
-    if (u >= s && u <= e) { pdf = e - s; return i; }
-  }
   int last = n - 2;
   if (last < 0) { pdf = 0.f; return 0; }
-  pdf = S.light_cdf[last + 1] - S.light_cdf[last];
+  int idx = -1;
+  float s_prev = uniform_load(S.light_cdf);
+  for (int i = 0; i + 1 < n; ++i) {  // the bounds are uniform, the loads scalar: no lane waits on another
+    float e = uniform_load(S.light_cdf + i + 1);
+    if (idx < 0 && u >= s_prev && u <= e) { idx = i; pdf = e - s_prev; }
+    s_prev = e;
+  }
+  if (idx >= 0) return idx;
+  pdf = uniform_load(S.light_cdf + last + 1) - uniform_load(S.light_cdf + last);
   return last;
 }
-
-// Light sampling step of Path/Volpath (pathtracer.cu:921-930): the light-pick
-// draw, two more draws, then Area::SampleLight (area.h:12-17 with
-// Triangle::SampleShape, Triangle.h:146-155) or Infinite::SampleLight
-// (infinite.h:16-35).  Outputs the shadow ray (dir, tmax).
 __device__ inline void sample_one_light(const DevScene& S, uint32_t& rng, V3 pos, V3& radiance, V3& sdir,
                                         float& stmax, float& lightPdf, float& choicePdf) {
   int idx = pick_light(S, rng_uniform(rng), choicePdf);
@@ -1439,10 +1457,12 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
               if (!S.inf.valid && S.n_lights <= kProbeCullLights) {
                 float pmaxD = maxcomp(vabs(mo));
                 for (int li = 0; li < S.n_lights; ++li) {
-                  int lprim = __float_as_int(S.lights[(size_t)li * kLightF4 + 4].w);
+                  int lprim = __float_as_int(uniform_load4(S.lights + (size_t)li * kLightF4 + 4).w);
+                  const float4* rec = S.isect + (size_t)lprim * kIsectF4;
                   float t, b1, b2;
                   bool last;
-                  if (prim_test(S, lprim, pos, mo, pmaxD, S.epsilon, INFINITY, t, b1, b2, last) &&
+                  if (prim_test_rec(S, uniform_load4(rec), uniform_load4(rec + 1), uniform_load4(rec + 2), pos, mo, pmaxD,
+                                    S.epsilon, INFINITY, t, b1, b2, last) &&
                       (t < ptmax || (t == ptmax && lprim > pseed) || pseed < 0)) {
                     ptmax = t;
                     pseed = lprim;

@@ -243,6 +243,8 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
 
 constexpr int kDefaultStreams = 3;
 constexpr int kMaxStreams = 8;
+// path state (80 B) + extension queues (2 x 52 B) + shadow (36 B) + probe (52 B) + three staging queues (3 x 36 B)
+constexpr double kBytesPerSlot = 380.0;
 
 static float gamma_n(int n) {  // common.h:111-114: double arithmetic, float result
   const double me = (double)1.192092896e-07F * 0.5;
@@ -414,7 +416,8 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   S.slots_per_iter = S.tiles_x * S.tiles_y * 64;
   r->y0 = 0; r->y1 = sc.height;
 
-  if (iters_in_flight <= 0) {
+  const bool default_pool = iters_in_flight <= 0;
+  if (default_pool) {
     // late bounces keep few rays alive: a batch needs tens of millions of paths
     // for their launches to fill the chip (the pools are sized for 288 GB of HBM:
     // 64 M slots x 380 B per stream)
@@ -423,6 +426,17 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   }
   if (n_streams <= 0) n_streams = kDefaultStreams;
   if (n_streams > kMaxStreams) n_streams = kMaxStreams;
+  if (default_pool) {
+    // the default pools take at most half of the memory that is free right now
+    // (other renderers or processes may share the GPU); a caller that states
+    // iters_in_flight gets what it asked for or an allocation error
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+      const double per_iter = (double)S.slots_per_iter * kBytesPerSlot * n_streams;
+      long long fit = (long long)((double)free_b * 0.5 / per_iter);
+      iters_in_flight = (int)std::max<long long>(1, std::min<long long>(iters_in_flight, fit));
+    }
+  }
   r->iters_in_flight = iters_in_flight;
   r->pool_slots = (uint32_t)S.slots_per_iter * (uint32_t)iters_in_flight;
   // shade grid: one wavefront per block, as many as are resident at once
@@ -819,6 +833,7 @@ int caster_reset_stats(caster_renderer* r) {
 }
 
 uint32_t caster_iterations(const caster_renderer* r) { return r ? r->iterations : 0; }
+int caster_iters_in_flight(const caster_renderer* r) { return r ? r->iters_in_flight : 0; }
 
 #ifdef CASTER_WALK_STATS
 // tuning builds only: copies and clears the k_trace step counters

@@ -4,7 +4,9 @@
 // scene.h:48-81.  Out-of-scope keys (bssrdf materials, the lt/bdpt/mlt/sppm/ir
 // integrators) are rejected with an error instead of
 // being silently mis-rendered.
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -195,6 +197,7 @@ const float kPI = 3.14159265358f;       // common.h:17-19
 const float kFOURPI = 12.56637061432f;
 
 bool load_impl(const char* filename, Scene& scene, std::string& err) {
+  const auto t_start = std::chrono::steady_clock::now();
   std::string file = filename;
   std::string base = file.substr(0, file.find_last_of('/') + 1);
   std::ifstream in(filename, std::ios::binary);
@@ -477,7 +480,14 @@ bool load_impl(const char* filename, Scene& scene, std::string& err) {
   for (size_t i = 0; i < prims.size(); ++i) prims[i].push_id = (int)i;
 
   // Scene::Init (scene.h:48-81)
+  const bool timing = getenv("CASTER_TIMING") != nullptr;
+  auto t_build = std::chrono::steady_clock::now();
+  if (timing) fprintf(stderr, "caster: scene parsed and meshes loaded in %.3f s (%zu primitives)\n",
+                      std::chrono::duration<double>(t_build - t_start).count(), prims.size());
   build_bvh(prims, scene.nodes, scene.root_box);
+  if (timing) fprintf(stderr, "caster: BVH built in %.3f s (%zu nodes)\n",
+                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count(),
+                      scene.nodes.size());
   scene.prims.swap(prims);
   scene.lights.resize(light_radiance.size());
   for (size_t i = 0; i < scene.prims.size(); ++i) {

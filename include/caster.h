@@ -138,6 +138,9 @@ int caster_get_kernel_times(caster_renderer* r, caster_kernel_times* out);
 int caster_get_stats(caster_renderer* r, caster_stats* out);
 int caster_reset_stats(caster_renderer* r);
 uint32_t caster_iterations(const caster_renderer* r);
+/* Iterations per batch of paths this renderer was given (the default depends on the
+   resolution and on the free device memory). */
+int caster_iters_in_flight(const caster_renderer* r);
 
 /* Replaces EndRender (pathtracer.cu:2683-2689); frees everything. */
 void caster_end(caster_renderer* r);
