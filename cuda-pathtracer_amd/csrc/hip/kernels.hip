@@ -883,6 +883,15 @@ __device__ inline V3 albedo(const DevScene& S, const Mat& m, V2 uv) {
 
 // --------------------------------------------------------------------- BSDFs
 // pathtracer.cu:45-178
+// The diffuse texture is looked up once per vertex: the BSDF functions below are
+// evaluated up to three times there (light sample, MIS sample, continuation)
+// with the same uv, and each would repeat the four texel fetches.
+__device__ inline void resolve_texture(const DevScene& S, Mat& m, V2 uv) {
+  if (m.tex != -1 && (m.type == 0 || m.type == 5)) {  // the materials that read it: Lambertian, Substrate
+    m.diffuse = albedo(S, m, uv);
+    m.tex = -1;
+  }
+}
 __device__ inline V3 spherical_dir(float s, float c, float phi) { return v3(s * fps::cos_(phi), s * fps::sin_(phi), c); }
 __device__ inline float dielectric_fresnel(float cosi, float cost, float etai, float etat) {
   float Rparl = (etat * cosi - etai * cost) / (etat * cosi + etai * cost);
@@ -1407,6 +1416,7 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
         V2 uv = is.uv;
         Mat m;
         load_mat(S, is.mat, m);
+        resolve_texture(S, m, uv);
         if ((bounces == 0 || specular) && is.light != -1) {
           // Area::Le (area.h:36-39)
           LightRec l;
@@ -1886,6 +1896,7 @@ __global__ __launch_bounds__(kWave) void k_shade_vpt(LaunchCtx L, RayQueue cur, 
             } else {
               Mat m;
               load_mat(S, is.mat, m);
+              resolve_texture(S, m, uv);
               if (!is_delta(m.type)) {
                 V3 Ld = v3(0.f, 0.f, 0.f);
                 V3 radiance, ldir;
