@@ -57,7 +57,7 @@ _lib = None
 
 # every symbol include/caster.h declares
 EXPORTS = [
-    "caster_scene_load", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams",
+    "caster_scene_load", "caster_scene_load_device", "caster_scene_get_bvh", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams",
     "caster_set_rows",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
     "caster_film_add_device", "caster_primary_ids", "caster_get_stats", "caster_reset_stats",
@@ -97,6 +97,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, fp = C.c_void_p, C.POINTER(C.c_float)
         L.caster_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.caster_scene_load_device.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.caster_scene_get_bvh.argtypes = [vp, fp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.caster_scene_free.argtypes = [vp]
         L.caster_scene_free.restype = None
         L.caster_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
@@ -135,15 +137,29 @@ class Scene:
     """A parsed scene file plus its BVH (the reference's ``Scene`` + ``GlobalConfig``
     after ``InitScene``, CUDA-PathTracer/tracer/parsescene.cpp:600-617)."""
 
-    def __init__(self, json_path):
+    def __init__(self, json_path, build_device=None):
+        """`build_device`: HIP device that builds the BVH (None: the host builds it)."""
         h = C.c_void_p()
-        _check(lib().caster_scene_load(os.fspath(json_path).encode(), C.byref(h)))
+        if build_device is None:
+            _check(lib().caster_scene_load(os.fspath(json_path).encode(), C.byref(h)))
+        else:
+            _check(lib().caster_scene_load_device(os.fspath(json_path).encode(), int(build_device), C.byref(h)))
         self._h = h
         info = SceneInfo()
         _check(lib().caster_scene_get_info(self._h, C.byref(info)))
         self.info = info
         self.width, self.height = info.width, info.height
         self.integrator = info.integrator
+
+    def bvh(self):
+        """(boxes (n_nodes, 6), meta (n_nodes, 4), primitive push ids (n_prims,)) of the binary tree."""
+        boxes = np.empty((self.info.n_nodes, 6), np.float32)
+        meta = np.empty((self.info.n_nodes, 4), np.int32)
+        ids = np.empty(self.info.n_prims, np.int32)
+        _check(lib().caster_scene_get_bvh(self._h, boxes.ctypes.data_as(C.POINTER(C.c_float)),
+                                          meta.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          ids.ctypes.data_as(C.POINTER(C.c_int32))))
+        return boxes, meta, ids
 
     def close(self):
         if getattr(self, "_h", None):

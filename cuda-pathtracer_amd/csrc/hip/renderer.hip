@@ -259,6 +259,11 @@ struct caster_scene {
   Scene scene;
 };
 
+namespace caster {
+bool build_bvh_gpu(int device, const std::vector<BBox>& boxes, const BBox& root_box, std::vector<Node>& nodes,
+                   std::vector<int>& order, std::string& err);  // bvh_build.hip
+}
+
 // One render stream with everything a batch of paths in flight needs.  Batches
 // are dealt to the streams in turn, so the tail of one batch's kernels (few rays
 // left in the late bounces, single-thread bookkeeping launches) overlaps the
@@ -601,6 +606,42 @@ int caster_scene_load(const char* json_path, caster_scene** out) {
     return fail(CASTER_ERR_SCENE, err);
   }
   *out = s;
+  return CASTER_OK;
+}
+
+static bool gpu_builder(void* ctx, const std::vector<BBox>& boxes, const BBox& root_box, std::vector<Node>& nodes,
+                        std::vector<int>& order, std::string& err) {
+  return build_bvh_gpu(*(int*)ctx, boxes, root_box, nodes, order, err);
+}
+
+int caster_scene_load_device(const char* json_path, int device_id, caster_scene** out) {
+  if (!json_path || !out) return fail(CASTER_ERR_ARG, "caster_scene_load_device: null argument");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device_id < 0 || device_id >= n_dev)
+    return fail(CASTER_ERR_DEVICE, "caster_scene_load_device: no such HIP device");
+  caster_scene* s = new caster_scene();
+  std::string err;
+  if (!load_scene(json_path, s->scene, err, gpu_builder, &device_id)) {
+    delete s;
+    return fail(CASTER_ERR_SCENE, err);
+  }
+  *out = s;
+  return CASTER_OK;
+}
+
+int caster_scene_get_bvh(const caster_scene* s, float* boxes, int32_t* meta, int32_t* prim_push_ids) {
+  if (!s) return fail(CASTER_ERR_ARG, "caster_scene_get_bvh: null scene");
+  const Scene& sc = s->scene;
+  for (size_t i = 0; i < sc.nodes.size(); ++i) {
+    const Node& n = sc.nodes[i];
+    if (boxes) {
+      float* b = boxes + 6 * i;
+      b[0] = n.lo.x; b[1] = n.lo.y; b[2] = n.lo.z; b[3] = n.hi.x; b[4] = n.hi.y; b[5] = n.hi.z;
+    }
+    if (meta) { int32_t* m = meta + 4 * i; m[0] = n.second; m[1] = n.leaf; m[2] = n.start; m[3] = n.end; }
+  }
+  if (prim_push_ids)
+    for (size_t i = 0; i < sc.prims.size(); ++i) prim_push_ids[i] = sc.prims[i].push_id;
   return CASTER_OK;
 }
 

@@ -117,31 +117,46 @@ struct Builder {
 
 }  // namespace
 
-void build_bvh(std::vector<Prim>& prims, std::vector<Node>& nodes, BBox& root_box) {
-  nodes.clear();
+void prim_boxes(const std::vector<Prim>& prims, std::vector<BBox>& boxes, BBox& root_box) {
+  boxes.resize(prims.size());
   root_box = BBox();
-  if (prims.empty()) return;
-  std::vector<BBox> boxes(prims.size());
   for (size_t i = 0; i < prims.size(); ++i) {
     boxes[i] = prim_bbox(prims[i]);
     root_box.expand(boxes[i]);
   }
+}
+
+void build_bvh_host(const std::vector<BBox>& boxes, const BBox& root_box, std::vector<Node>& nodes, std::vector<int>& order) {
+  nodes.clear();
+  order.clear();
+  if (boxes.empty()) return;
   Builder b{boxes, {}, {}, {}, nodes, {}};
-  b.centres.resize(prims.size());
-  b.order.resize(prims.size());
-  b.scratch.resize(prims.size());
-  for (size_t i = 0; i < prims.size(); ++i) {
+  b.centres.resize(boxes.size());
+  b.order.resize(boxes.size());
+  b.scratch.resize(boxes.size());
+  for (size_t i = 0; i < boxes.size(); ++i) {
     b.centres[i] = boxes[i].centre();
     b.order[i] = (int)i;
   }
-  b.out_order.reserve(prims.size());
-  nodes.reserve(prims.size() / 2 + 16);
-  b.split(0, (int)prims.size(), root_box);
+  b.out_order.reserve(boxes.size());
+  nodes.reserve(boxes.size() / 2 + 16);
+  b.split(0, (int)boxes.size(), root_box);
+  order.swap(b.out_order);
+}
 
+void apply_prim_order(std::vector<Prim>& prims, const std::vector<int>& order) {
   std::vector<Prim> sorted;
   sorted.reserve(prims.size());
-  for (int id : b.out_order) sorted.push_back(prims[id]);
+  for (int id : order) sorted.push_back(prims[id]);
   prims.swap(sorted);
+}
+
+void build_bvh(std::vector<Prim>& prims, std::vector<Node>& nodes, BBox& root_box) {
+  std::vector<BBox> boxes;
+  std::vector<int> order;
+  prim_boxes(prims, boxes, root_box);
+  build_bvh_host(boxes, root_box, nodes, order);
+  apply_prim_order(prims, order);
 }
 
 }  // namespace caster

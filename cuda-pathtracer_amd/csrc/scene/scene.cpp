@@ -196,7 +196,7 @@ float tri_area(const Prim& p) {  // Triangle.h:81-85
 const float kPI = 3.14159265358f;       // common.h:17-19
 const float kFOURPI = 12.56637061432f;
 
-bool load_impl(const char* filename, Scene& scene, std::string& err) {
+bool load_impl(const char* filename, Scene& scene, std::string& err, BvhBuilder builder, void* builder_ctx) {
   const auto t_start = std::chrono::steady_clock::now();
   std::string file = filename;
   std::string base = file.substr(0, file.find_last_of('/') + 1);
@@ -484,7 +484,15 @@ bool load_impl(const char* filename, Scene& scene, std::string& err) {
   auto t_build = std::chrono::steady_clock::now();
   if (timing) fprintf(stderr, "caster: scene parsed and meshes loaded in %.3f s (%zu primitives)\n",
                       std::chrono::duration<double>(t_build - t_start).count(), prims.size());
-  build_bvh(prims, scene.nodes, scene.root_box);
+  if (builder) {
+    std::vector<BBox> boxes;
+    std::vector<int> order;
+    prim_boxes(prims, boxes, scene.root_box);
+    if (!builder(builder_ctx, boxes, scene.root_box, scene.nodes, order, err)) return false;
+    apply_prim_order(prims, order);
+  } else {
+    build_bvh(prims, scene.nodes, scene.root_box);
+  }
   if (timing) fprintf(stderr, "caster: BVH built in %.3f s (%zu nodes)\n",
                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count(),
                       scene.nodes.size());
@@ -518,9 +526,9 @@ bool load_impl(const char* filename, Scene& scene, std::string& err) {
 
 }  // namespace
 
-bool load_scene(const char* path, Scene& out, std::string& err) {
+bool load_scene(const char* path, Scene& out, std::string& err, BvhBuilder builder, void* builder_ctx) {
   try {
-    return load_impl(path, out, err);
+    return load_impl(path, out, err, builder, builder_ctx);
   } catch (const std::exception& e) {
     err = e.what();
     return false;

@@ -145,11 +145,19 @@ struct Scene {
 // Parses `path` (reference schema, parsescene.cpp:46-598), loads meshes and
 // textures relative to it, builds the BVH and the light CDF (scene.h:48-81).
 // Returns false and fills `err` on failure.
-bool load_scene(const char* path, Scene& out, std::string& err);
+// A BVH builder other than the host one (the GPU build): fills `nodes` (pre-order) and `order`
+// (primitive indices leaf by leaf) from the primitive boxes; must deliver what build_bvh_host does.
+typedef bool (*BvhBuilder)(void* ctx, const std::vector<BBox>& boxes, const BBox& root_box, std::vector<Node>& nodes,
+                           std::vector<int>& order, std::string& err);
+bool load_scene(const char* path, Scene& out, std::string& err, BvhBuilder builder = nullptr, void* builder_ctx = nullptr);
 
 // bvh.cpp
 BBox prim_bbox(const Prim& p);
 void build_bvh(std::vector<Prim>& prims, std::vector<Node>& nodes, BBox& root_box);
+// its three steps
+void prim_boxes(const std::vector<Prim>& prims, std::vector<BBox>& boxes, BBox& root_box);
+void build_bvh_host(const std::vector<BBox>& boxes, const BBox& root_box, std::vector<Node>& nodes, std::vector<int>& order);
+void apply_prim_order(std::vector<Prim>& prims, const std::vector<int>& order);
 
 // mesh_io.cpp
 struct RawMesh {

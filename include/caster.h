@@ -54,6 +54,17 @@ typedef struct caster_stats {
 /* Replaces InitScene (parsescene.cpp:600-617): parses the JSON scene file,
    loads its meshes/textures, builds the BVH and the light distribution. */
 int caster_scene_load(const char* json_path, caster_scene** out);
+/* caster_scene_load with the BVH built on HIP device `device_id` instead of on the
+   host (replaces BVH::build, bvh.cpp:8-180, which dominates the load time of
+   large meshes).  The tree and the primitive order are those of the host build,
+   bit for bit. */
+int caster_scene_load_device(const char* json_path, int device_id, caster_scene** out);
+/* Parity hook (no counterpart in the reference): the pre-order binary tree.
+   boxes: n_nodes*6 floats (lo.xyz, hi.xyz); meta: n_nodes*4 ints (second child,
+   leaf flag, first and last primitive of a leaf or -1); prim_push_ids: for every
+   primitive in tree order, its index in the scene file's push order.  Any
+   pointer may be null. */
+int caster_scene_get_bvh(const caster_scene* s, float* boxes, int32_t* meta, int32_t* prim_push_ids);
 void caster_scene_free(caster_scene* s);
 int caster_scene_get_info(const caster_scene* s, caster_scene_info* out);
 
