@@ -21,7 +21,10 @@
 
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -305,6 +308,11 @@ bool build_bvh_gpu(int device, const std::vector<BBox>& boxes, const BBox& root_
   order.clear();
   if (n == 0) return true;
   BVHCHECK(hipSetDevice(device));
+  const bool timing = getenv("CASTER_TIMING") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+  };
   std::vector<void*> allocs;
   auto cleanup = [&]() { for (void* p : allocs) (void)hipFree(p); };
   auto alloc = [&](auto** out, size_t count) {
@@ -349,6 +357,8 @@ bool build_bvh_gpu(int device, const std::vector<BBox>& boxes, const BBox& root_
   BVHTRY(alloc(&tmp, tmp_bytes));
 
   const int nb = (n + kBlock - 1) / kBlock;
+  const auto t_levels = std::chrono::steady_clock::now();
+  const double s_setup = since(t_start);
   hipLaunchKernelGGL(k_prepare, dim3(nb), dim3(kBlock), 0, 0, blo, bhi, centre, order_a, seg_a, n);
   {  // the root
     float lo[3] = {root_box.lo.x, root_box.lo.y, root_box.lo.z}, hi[3] = {root_box.hi.x, root_box.hi.y, root_box.hi.z};
@@ -398,11 +408,17 @@ bool build_bvh_gpu(int device, const std::vector<BBox>& boxes, const BBox& root_
   BVHTRY(alloc(&out, total));
   hipLaunchKernelGGL(k_emit, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, N, total, out);
   BVHTRY(hipGetLastError());
+  BVHTRY(hipDeviceSynchronize());
+  const double s_levels = since(t_levels);
+  const auto t_down = std::chrono::steady_clock::now();
   nodes.resize((size_t)total);
   order.resize((size_t)n);
   BVHTRY(hipMemcpy(nodes.data(), out, (size_t)total * sizeof(Node), hipMemcpyDeviceToHost));
   BVHTRY(hipMemcpy(order.data(), ord_in, (size_t)n * 4, hipMemcpyDeviceToHost));
   cleanup();
+  if (timing)
+    fprintf(stderr, "caster: GPU BVH build: %zu levels, %d nodes; allocate + upload %.4f s, kernels %.4f s (%.1f M primitives/s), download + free %.4f s\n",
+            levels.size(), total, s_setup, s_levels, n / s_levels / 1e6, since(t_down));
   return true;
 #undef BVHTRY
 }
