@@ -25,6 +25,7 @@ SMALL_SCENES = {
     "cornell_ao": dict(name="cornell_ao", width=96, height=96),
     "cornell_pt": dict(name="cornell_pt", width=96, height=96),
     "cornell_vpt": dict(name="cornell_vpt", width=96, height=96, depth=8),
+    "cornell_meshlight": dict(name="cornell_meshlight", width=96, height=96),
     "cornell_smoke": dict(name="cornell_smoke", width=96, height=96, depth=8),
     "knot_pt": dict(name="knot_pt", width=96, height=96, detail=0.08),
     "stairs_pt": dict(name="stairs_pt", width=128, height=72, detail=0.08),

@@ -14,7 +14,7 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 
-SPP = {"cornell_ao": 8, "cornell_pt": 8, "cornell_vpt": 4, "cornell_smoke": 4, "knot_pt": 4, "stairs_pt": 4, "car_pt": 4, "car_env": 4,
+SPP = {"cornell_ao": 8, "cornell_pt": 8, "cornell_vpt": 4, "cornell_smoke": 4, "cornell_meshlight": 6, "knot_pt": 4, "stairs_pt": 4, "car_pt": 4, "car_env": 4,
        "odd_size": 4}
 
 

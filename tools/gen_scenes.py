@@ -12,6 +12,7 @@ reference's JSON schema (CUDA-PathTracer/tracer/parsescene.cpp:46-598):
                textured Lambertian ground
   stairs_pt    "staircase2" stand-in: RoughConductor / RoughDielectric /
                Substrate materials, Line railings
+  cornell_meshlight  Cornell box lit by 34 emissive triangles
   cornell_smoke  Cornell box with a heterogeneous medium (density grid) in an index-matched box
   cornell_vpt  Cornell box with a homogeneous medium inside an index-matched
                box boundary and a glass sphere, volumetric path tracing
@@ -287,6 +288,25 @@ def scene_cornell_pt(out, a):
     return s
 
 
+def scene_cornell_meshlight(out, a):
+    """Cornell box lit by a tessellated panel (32 emissive triangles: one area light each, a long
+    light distribution) and a small second panel on the back wall."""
+    s = scene_cornell_pt(out, a)
+    panel = Mesh()
+    n = 4
+    for i in range(n):
+        for j in range(n):
+            x0, x1 = -0.4 + 0.8 * i / n, -0.4 + 0.8 * (i + 1) / n
+            z0, z1 = -0.35 + 0.6 * j / n, -0.35 + 0.6 * (j + 1) / n
+            panel.quad([x0, 1.98, z0], [x1, 1.98, z0], [x1, 1.98, z1], [x0, 1.98, z1], [0, -1, 0])
+    panel.write_obj(os.path.join(out, "panel.obj"))
+    spot = Mesh(); spot.quad([-0.2, 1.2, -0.98], [0.2, 1.2, -0.98], [0.2, 1.5, -0.98], [-0.2, 1.5, -0.98], [0, 0, 1])
+    spot.write_obj(os.path.join(out, "spot.obj"))
+    s["light"] = [{"mesh": "panel.obj", "material": "matte", "radiance": [9, 7, 3]},
+                  {"mesh": "spot.obj", "material": "matte", "radiance": [2, 4, 9]}]
+    return s
+
+
 def scene_cornell_vpt(out, a):
     cornell_meshes(out)
     fog = Mesh(); fog.box([0.0, 0.8, 0.0], [0.75, 0.55, 0.75], 0.0)
@@ -477,7 +497,7 @@ def scene_car_pt(out, a):
 
 SCENES = {
     "cornell_ao": scene_cornell_ao, "cornell_pt": scene_cornell_pt, "cornell_vpt": scene_cornell_vpt,
-    "cornell_smoke": scene_cornell_smoke,
+    "cornell_smoke": scene_cornell_smoke, "cornell_meshlight": scene_cornell_meshlight,
     "knot_pt": scene_knot_pt, "stairs_pt": scene_stairs_pt, "car_pt": scene_car_pt,
 }
 
