@@ -1459,26 +1459,36 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
               absdot = fabsf(dot(mo, nor));
 #if CASTER_PROBE_CULL
               // The probe only contributes when its closest hit is an emitter (no
-              // environment light here).  With few emitters their triangles are
-              // tested first, with the very test the traversal uses: if none is
-              // hit, the closest hit cannot be one and no ray is sent; otherwise
-              // the ray starts out holding the nearest emitter hit, so that the
-              // traversal only looks for something at least as close.
-              if (!S.inf.valid && S.n_lights <= kProbeCullLights) {
-                float pmaxD = maxcomp(vabs(mo));
-                for (int li = 0; li < S.n_lights; ++li) {
-                  int lprim = __float_as_int(uniform_load4(S.lights + (size_t)li * kLightF4 + 4).w);
-                  const float4* rec = S.isect + (size_t)lprim * kIsectF4;
-                  float t, b1, b2;
-                  bool last;
-                  if (prim_test_rec(S, uniform_load4(rec), uniform_load4(rec + 1), uniform_load4(rec + 2), pos, mo, pmaxD,
-                                    S.epsilon, INFINITY, t, b1, b2, last) &&
-                      (t < ptmax || (t == ptmax && lprim > pseed) || pseed < 0)) {
-                    ptmax = t;
-                    pseed = lprim;
+              // environment light here), so a ray that cannot reach one is not
+              // sent.  With few emitters their triangles are tested with the very
+              // test the traversal uses: if none is hit, the closest hit cannot be
+              // one; otherwise the ray starts out holding the nearest emitter hit,
+              // so that the traversal only looks for something at least as close.
+              if (!S.inf.valid) {
+                // first the padded box around all emitters: a ray that misses it cannot hit one
+                float tn;
+                bool reach = S.n_lights > 0 &&
+                             box_test(v3(S.emit_lo), v3(S.emit_hi), pos, v3(1.f / mo.x, 1.f / mo.y, 1.f / mo.z), INFINITY,
+                                      S.box_scale, tn);
+                if (!reach) {
+                  want_probe = false;
+                  py = make_float4(0, 0, 0, 0);
+                } else if (S.n_lights <= kProbeCullLights) {
+                  float pmaxD = maxcomp(vabs(mo));
+                  for (int li = 0; li < S.n_lights; ++li) {
+                    int lprim = __float_as_int(uniform_load4(S.lights + (size_t)li * kLightF4 + 4).w);
+                    const float4* rec = S.isect + (size_t)lprim * kIsectF4;
+                    float t, b1, b2;
+                    bool last;
+                    if (prim_test_rec(S, uniform_load4(rec), uniform_load4(rec + 1), uniform_load4(rec + 2), pos, mo, pmaxD,
+                                      S.epsilon, INFINITY, t, b1, b2, last) &&
+                        (t < ptmax || (t == ptmax && lprim > pseed) || pseed < 0)) {
+                      ptmax = t;
+                      pseed = lprim;
+                    }
                   }
+                  if (pseed < 0) { want_probe = false; py = make_float4(0, 0, 0, 0); }
                 }
-                if (pseed < 0) { want_probe = false; py = make_float4(0, 0, 0, 0); }
               }
 #endif
             }

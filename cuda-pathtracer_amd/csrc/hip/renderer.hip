@@ -415,6 +415,20 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   S.epsilon = sc.epsilon;
   S.g1 = gamma_n(1); S.g2 = gamma_n(2); S.g3 = gamma_n(3);
   S.box_scale = 1 + 2 * S.g3;
+  {
+    // Bounds of the emitters, for rejecting BSDF-sampled probe rays that cannot reach one.  The
+    // pad (1e-3 of the box's size and position) is some four orders of magnitude above the
+    // rounding error of the ray/triangle and ray/box tests, so a ray that any of those tests could
+    // report as hitting an emitter passes this box.
+    BBox eb;
+    for (const Light& l : sc.lights)
+      for (int k = 0; k < 3; ++k) eb.expand(sc.prims[l.prim].v[k].v);
+    f3 d = eb.hi - eb.lo;
+    float pad = sc.lights.empty() ? 0.f
+                                  : 1e-3f * (fps::fmax_(fps::fmax_(d.x, d.y), d.z) + fps::fmax_(maxabs(eb.lo), maxabs(eb.hi))) + 1e-6f;
+    S.emit_lo[0] = eb.lo.x - pad; S.emit_lo[1] = eb.lo.y - pad; S.emit_lo[2] = eb.lo.z - pad;
+    S.emit_hi[0] = eb.hi.x + pad; S.emit_hi[1] = eb.hi.y + pad; S.emit_hi[2] = eb.hi.z + pad;
+  }
   S.integrator = sc.integrator; S.maxDepth = sc.maxDepth; S.maxDist = sc.maxDist;
   S.width = sc.width; S.height = sc.height;
   S.tiles_x = (sc.width + 7) / 8; S.tiles_y = (sc.height + 7) / 8;
