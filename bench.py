@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="HIP streams batches are dealt to (0: library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (roofline then uses no counts)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the one-stream repeat (profiling runs)")
     ap.add_argument("--shard", choices=["spp", "tile"], default="spp")
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo + --share-gpu rehearses N>1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses device 0 (rehearsal only)")
@@ -278,6 +279,8 @@ def main():
                         tris_per_ray=sum(counts["tris"][kind] for kind in kinds) / max(o_rays, 1))
         # one-stream repeat: each launch has the GPU to itself
         try:
+            if a.no_exclusive:
+                raise caster.CasterError(0, "skipped (--no-exclusive)")
             r1 = caster.Renderer(scene, dev_index, r.iters_in_flight, 1)
             if rows != (0, scene.height):
                 r1.set_rows(*rows)
