@@ -224,8 +224,14 @@ def main():
             o.render(1, 1, 1, counts=c1, rows=(y_mid, min(y_mid + 4, scene.height)))
             tc1 = time.perf_counter() - t0
             counts = c.as_dict()
+            cpu_model = ""
+            try:
+                with open("/proc/cpuinfo") as f:
+                    cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+            except OSError:
+                pass
             out["cpu_baseline"] = {
-                "value": n_cpu / tc / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+                "value": n_cpu / tc / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
                 "sample": "%d samples: 1 spp on every 8th block of 8 scanlines of the same %dx%d frame" % (
                     n_cpu, scene.width, scene.height),
                 "single_thread_msamples_per_s": c1.samples / tc1 / 1e6,
