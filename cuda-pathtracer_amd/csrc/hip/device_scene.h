@@ -91,12 +91,19 @@ struct PathState {
   float4* pend_x;
   float4* pend_y;
   float4* beta_prev;
+  // volumetric integrator on queues only (null otherwise): operands of the light-sampled term,
+  // which can only be evaluated once the transmittance walk of the shadow ray is over
+  float4* pend_z;  // radiance | lightPdf * choicePdf
+  float4* pend_w;  // transmittance so far | medium of the shadow ray's current segment
+  float4* pend_v;  // |cos| of the probe direction, |cos| of the light direction, medium of the vertex's ray
 };
 
 constexpr uint32_t kFBounceMask = 0xffffu;       // bounce counter
 constexpr uint32_t kFSpecular = 1u << 16;
 constexpr uint32_t kFPending = 1u << 17;
 constexpr uint32_t kFPendingY = 1u << 18;        // pend_y holds a BSDF-sampled term (else it counts as zero)
+constexpr uint32_t kFPendingM = 1u << 19;        // vpt: the pending term is that of a scattering event in a medium
+constexpr uint32_t kFPendingX = 1u << 28;        // vpt: the pending term has a light-sampled part
 constexpr uint32_t kFMediumShift = 20;           // bits 20..27: medium index + 1
 constexpr uint32_t kFMediumMask = 0xffu << kFMediumShift;
 

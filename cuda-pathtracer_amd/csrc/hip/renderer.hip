@@ -242,6 +242,7 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
 }
 
 constexpr int kDefaultStreams = 3;
+constexpr int kTrQueuePasses = 3;  // Tr() segments of the volumetric integrator's shadow rays done on queues
 constexpr int kMaxStreams = 8;
 // path state (80 B) + extension queues (2 x 52 B) + shadow (36 B) + probe (52 B) + three staging queues (3 x 36 B)
 constexpr double kBytesPerSlot = 380.0;
@@ -272,11 +273,15 @@ struct Lane {
   hipStream_t stream = nullptr;
   PathState P{};
   RayQueue ext[2]{}, shadow{}, probe{};
-  uint32_t* counters = nullptr;  // queue lengths: ext0, ext1, shadow, probe; then 3 x kWorkShards work counters
+  RayQueue tr1{};  // volumetric integrator on queues: shadow rays going on past an index-matched boundary
+  uint32_t* counters = nullptr;  // queue lengths: ext0, ext1, shadow, probe, tr1; then 3 x kWorkShards work counters
   WalkAux aux{};
   StageArea stage{};
   Stats* stats = nullptr;
   hipEvent_t finish_done = nullptr;  // recorded after the lane's latest k_finish
+  // batch under way between the two halves of its submission
+  uint32_t batch_first = 0, batch_n = 0;
+  int batch_cur = 0, batch_b = 0;
 };
 
 struct caster_renderer {
@@ -289,6 +294,7 @@ struct caster_renderer {
   uint32_t work_init = 0;
   int walk_grid = 0;
   int shade_grid = 0;
+  bool vpt_queues = false;  // volumetric integrator with its shadow and probe rays on queues (no density grid in the scene)
   float* acc = nullptr;
   float* film_tmp = nullptr;
   int32_t* ids = nullptr;
@@ -353,8 +359,14 @@ static int alloc_lane(caster_renderer* r, Lane& ln) {
   HIPCHECK(hipMemset(ln.counters, 0, (64 + 3 * kWorkShards * kWorkPad) * sizeof(uint32_t)));
   if ((rc = alloc_queue(r, ln.ext[0], n, true, ln.counters + 0))) return rc;
   if ((rc = alloc_queue(r, ln.ext[1], n, true, ln.counters + 1))) return rc;
-  if ((rc = alloc_queue(r, ln.shadow, n, false, ln.counters + 2))) return rc;
+  if ((rc = alloc_queue(r, ln.shadow, n, r->vpt_queues, ln.counters + 2))) return rc;
   if ((rc = alloc_queue(r, ln.probe, n, true, ln.counters + 3))) return rc;
+  if (r->vpt_queues) {
+    if ((rc = alloc_queue(r, ln.tr1, n, true, ln.counters + 4))) return rc;
+    if ((rc = dev_alloc(r, &ln.P.pend_z, n))) return rc;
+    if ((rc = dev_alloc(r, &ln.P.pend_w, n))) return rc;
+    if ((rc = dev_alloc(r, &ln.P.pend_v, n))) return rc;
+  }
   // every shade wavefront owns a staging region large enough for all paths it can be given
   uint32_t rounds = (n + kWave - 1) / kWave;
   uint32_t per = (rounds + (uint32_t)r->shade_grid - 1) / (uint32_t)r->shade_grid;
@@ -461,8 +473,10 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   // shade grid: one wavefront per block, as many as are resident at once
   {
     int per_cu = 8;
+    r->vpt_queues = sc.integrator == IT_VPT && !sc.has_heterogeneous;
     const void* fn = sc.integrator == IT_AO ? (const void*)k_shade_ao
-                     : sc.integrator == IT_VPT ? (const void*)k_shade_vpt : (const void*)k_shade_pt;
+                     : sc.integrator == IT_VPT ? (r->vpt_queues ? (const void*)k_shade_vptq : (const void*)k_shade_vpt)
+                                               : (const void*)k_shade_pt;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 8;
     if (per_cu > 20) per_cu = 20;  // the vpt shade stage indexes the spill area sized for 20 wavefronts per CU
     r->shade_grid = r->n_cu * per_cu;
@@ -520,11 +534,15 @@ static void collect_timers(caster_renderer* r) {
   r->pending_events.clear();
 }
 
-// Enqueues one batch of `n` iterations starting at `first` on the next stream.
-static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
+// Enqueues one batch of `n` iterations starting at `first` on stream `lane`, in two halves:
+// `tail` false submits the camera rays and the first maxDepth rounds, which need nothing from
+// the host; `tail` true (same lane, after the heads of the other lanes have been submitted, so
+// that they run meanwhile) submits what does -- the volumetric integrator's extra rounds, whose
+// number depends on a queue length -- and the film accumulation.
+static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t first, uint32_t n) {
   const DevScene& S = r->S;
-  Lane& ln = r->lanes[r->next_lane];
-  r->next_lane = (r->next_lane + 1) % (uint32_t)r->lanes.size();
+  Lane& ln = r->lanes[lane];
+  if (tail) { first = ln.batch_first; n = ln.batch_n; }
   hipStream_t st = ln.stream;
   LaunchCtx L = ctx_of(r, ln);
   const uint32_t total = (uint32_t)S.slots_per_iter * n;
@@ -532,17 +550,61 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
   auto aux_for = [&](int which) { WalkAux a = ln.aux; a.work = ln.counters + 64 + which * kWorkShards * kWorkPad; return a; };
   const int shade_grid = r->shade_grid;
   const int gen_grid = (int)std::min<uint32_t>((total + kWave - 1) / kWave, (uint32_t)r->n_cu * 32);
-  int cur = 0;
-  {
-    ScopedTimer t(r, st, CASTER_K_GENERATE);
-    hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1);
+  int cur = tail ? ln.batch_cur : 0;
+  if (!tail) {
+    {
+      ScopedTimer t(r, st, CASTER_K_GENERATE);
+      hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1);
+    }
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, total);
+    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, ln.ext[1].count, ln.shadow.count, ln.probe.count, 0u, ln.counters + 64,
+                       3u * kWorkShards, r->work_init);
   }
-  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, total);
-  hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                     (const uint32_t*)nullptr, ln.ext[1].count, ln.shadow.count, ln.probe.count, 0u, ln.counters + 64,
-                     3u * kWorkShards, r->work_init);
   const uint32_t live_rays = (uint32_t)S.width * (uint32_t)(r->y1 - r->y0) * n;
+  bool failed = false;
+  // One round of the volumetric integrator with everything on queues: the shadow rays are
+  // advanced a Tr() segment at a time (closest-hit pass, then k_tr_step) until none is left.
+  auto bounce_vptq = [&](int b) {
+    RayQueue& q = ln.ext[cur];
+    ShadeQueues out{ln.ext[cur ^ 1], ln.shadow, ln.probe};
+    {
+      ScopedTimer t(r, st, CASTER_K_EXTEND);
+      hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, q, aux_for(0));
+    }
+    {
+      ScopedTimer t(r, st, CASTER_K_SHADE);
+      hipLaunchKernelGGL(k_shade_vptq, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
+    }
+    RayQueue* tq[2] = {&ln.shadow, &ln.tr1};
+    int tcur = 0;
+    for (int it = 0; it < kTrQueuePasses; ++it) {
+      hipLaunchKernelGGL(k_add_stat, dim3(1), dim3(1), 0, st, ln.stats, 3, (const uint32_t*)tq[tcur]->count);
+      hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
+                         ln.counters + 64 + 1 * kWorkShards * kWorkPad, (uint32_t)kWorkShards, r->work_init);
+      {
+        ScopedTimer t(r, st, CASTER_K_SHADOW);
+        hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, *tq[tcur], aux_for(1));
+      }
+      hipLaunchKernelGGL(k_tr_step, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
+      hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, tq[tcur]->count, 0u);
+      tcur ^= 1;
+    }
+    // whatever is still under way is walked to its end lane by lane
+    hipLaunchKernelGGL(k_tr_finish, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], ln.aux);
+    {
+      ScopedTimer t(r, st, CASTER_K_PROBE);
+      hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.probe, aux_for(2));
+    }
+    hipLaunchKernelGGL(k_probe_resolve_vpt, dim3(shade_grid), dim3(kWave), 0, st, L, ln.probe);
+    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)q.count, (const uint32_t*)nullptr,
+                       (const uint32_t*)ln.probe.count, q.count, tq[tcur]->count, ln.probe.count, b == 0 ? live_rays : 0u,
+                       ln.counters + 64, 3u * kWorkShards, r->work_init);
+    cur ^= 1;
+  };
   auto bounce = [&](int b) {
+    if (r->vpt_queues) { bounce_vptq(b); return; }
     RayQueue& q = ln.ext[cur];
     ShadeQueues out{ln.ext[cur ^ 1], ln.shadow, ln.probe};
     {
@@ -575,24 +637,29 @@ static int enqueue_batch(caster_renderer* r, uint32_t first, uint32_t n) {
                        ln.probe.count, b == 0 ? live_rays : 0u, ln.counters + 64, 3u * kWorkShards, r->work_init);
     cur ^= 1;
   };
-  if (S.integrator == IT_AO) {
-    bounce(0);
-  } else if (S.integrator == IT_PT) {
-    for (int b = 0; b < S.maxDepth; ++b) bounce(b);
-  } else {
+  if (!tail) {
+    if (S.integrator == IT_AO) bounce(0);
+    else for (int b = 0; b < S.maxDepth; ++b) bounce(b);
+    ln.batch_first = first; ln.batch_n = n; ln.batch_cur = cur; ln.batch_b = S.maxDepth;
+    HIPCHECK(hipGetLastError());
+    return CASTER_OK;
+  }
+  if (S.integrator == IT_VPT) {
     // Boundary crossings do not consume a bounce (pathtracer.cu:1106-1113), so
     // the number of rounds is data dependent: after maxDepth rounds keep going
     // while the queue is non-empty.
-    int b = 0;
-    for (; b < S.maxDepth; ++b) bounce(b);
-    for (;; ++b) {
+    int b = ln.batch_b;
+    // (the queue length is only asked for every few rounds: a round over an empty
+    // queue costs a handful of empty launches, a host round trip stalls the stream)
+    for (;;) {
       uint32_t left = 0;
       HIPCHECK(hipMemcpyAsync(&left, ln.ext[cur].count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIPCHECK(hipStreamSynchronize(st));
       if (left == 0 || b > S.maxDepth + kMaxCrossings) break;
-      bounce(b);
+      for (int k = 0; k < 4; ++k, ++b) bounce(b);
     }
   }
+  if (failed) return fail(CASTER_ERR_DEVICE, "reading a queue length failed");
   // a pixel's samples are added in iteration order whatever stream traced them
   if (r->last_finish && r->last_finish != ln.finish_done) HIPCHECK(hipStreamWaitEvent(st, r->last_finish, 0));
   {
@@ -720,11 +787,21 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
     r->iterations = 0;
   }
   uint32_t done = 0;
+  const uint32_t n_lanes = (uint32_t)r->lanes.size();
   while (done < n_iter) {
-    uint32_t n = std::min<uint32_t>(n_iter - done, (uint32_t)r->iters_in_flight);
-    int rc = enqueue_batch(r, first_iter + done, n);
-    if (rc) return rc;
-    done += n;
+    // one batch per stream: first what needs no host round trip, then the rest in batch order
+    uint32_t heads = 0;
+    for (; heads < n_lanes && done < n_iter; ++heads) {
+      uint32_t n = std::min<uint32_t>(n_iter - done, (uint32_t)r->iters_in_flight);
+      int rc = enqueue_batch(r, (r->next_lane + heads) % n_lanes, false, first_iter + done, n);
+      if (rc) return rc;
+      done += n;
+    }
+    for (uint32_t k = 0; k < heads; ++k) {
+      int rc = enqueue_batch(r, (r->next_lane + k) % n_lanes, true, 0, 0);
+      if (rc) return rc;
+    }
+    r->next_lane = (r->next_lane + heads) % n_lanes;
   }
   r->iterations += n_iter;
   r->samples += (uint64_t)r->S.width * (uint64_t)(r->y1 - r->y0) * n_iter;
