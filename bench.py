@@ -32,6 +32,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+# what each synthetic scene of tools/gen_scenes.py stands in for among the benchmark configurations
+STAND_IN = {"car_pt": "bmw-m6 stand-in", "stairs_pt": "staircase2 stand-in", "knot_pt": "teapot-full stand-in",
+            "cornell_ao": "Cornell box", "cornell_pt": "Cornell box", "cornell_vpt": "Cornell box with a homogeneous medium",
+            "cornell_smoke": "Cornell box with a heterogeneous medium", "cornell_meshlight": "Cornell box with a mesh light"}
 
 
 def scene_path(name, detail, width, height, depth, rank, barrier):
@@ -194,8 +198,9 @@ def main():
             "invalid_samples": rays[5],
             "stack_overflow": rays[6],
             "config": {
-                "workload": "%s (bmw-m6 stand-in, %d primitives, %d BVH nodes) %dx%d %s maxDepth %d" % (
-                    a.scene, scene.info.n_prims, scene.info.n_nodes, scene.width, scene.height,
+                "workload": "%s (%s, %d primitives, %d BVH nodes) %dx%d %s maxDepth %d" % (
+                    a.scene, STAND_IN.get(a.scene, "synthetic scene"), scene.info.n_prims, scene.info.n_nodes,
+                    scene.width, scene.height,
                     caster.INTEGRATOR_NAMES[scene.integrator], scene.info.max_depth),
                 "spp_per_step": spp,
                 "sharding": ("none" if world == 1 else
