@@ -40,7 +40,7 @@ constexpr uint32_t kPrimLastInLeaf = 4u;    // leaf ranges end at the primitive 
 struct DevCamera {
   float pos[3], u[3], v[3], w[3];
   float res_x, res_y, distance, apertureRadius, focalDistance;
-  float half_w, half_h, p2s_x, p2s_y, ratio;
+  float half_w, half_h, p2s_x, p2s_y, ratio, area;
   int environment, medium, filmic;
 };
 

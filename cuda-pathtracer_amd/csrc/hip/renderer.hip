@@ -418,7 +418,7 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   for (int k = 0; k < 4; ++k) { dst[k][0] = src[k]->x; dst[k][1] = src[k]->y; dst[k][2] = src[k]->z; }
   dc.res_x = c.res_x; dc.res_y = c.res_y; dc.distance = c.distance;
   dc.apertureRadius = c.apertureRadius; dc.focalDistance = c.focalDistance;
-  dc.half_w = c.half_w; dc.half_h = c.half_h; dc.p2s_x = c.p2s_x; dc.p2s_y = c.p2s_y; dc.ratio = c.ratio;
+  dc.half_w = c.half_w; dc.half_h = c.half_h; dc.p2s_x = c.p2s_x; dc.p2s_y = c.p2s_y; dc.ratio = c.ratio; dc.area = c.area;
   dc.environment = c.environment; dc.medium = c.medium; dc.filmic = c.filmic;
   S.inf.valid = sc.infinite.valid; S.inf.w = sc.infinite.w; S.inf.h = sc.infinite.h;
   S.inf.radius = sc.infinite.radius;
@@ -477,7 +477,8 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     r->vpt_queues = sc.integrator == IT_VPT && !sc.has_heterogeneous;
     const void* fn = sc.integrator == IT_AO ? (const void*)k_shade_ao
                      : sc.integrator == IT_VPT ? (r->vpt_queues ? (const void*)k_shade_vptq : (const void*)k_shade_vpt)
-                                               : (const void*)k_shade_pt;
+                     : sc.integrator == IT_LT ? (const void*)k_shade_lt
+                                              : (const void*)k_shade_pt;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 8;
     if (per_cu > 20) per_cu = 20;  // the vpt shade stage indexes the spill area sized for 20 wavefronts per CU
     r->shade_grid = r->n_cu * per_cu;
@@ -555,7 +556,11 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
   if (!tail) {
     {
       ScopedTimer t(r, st, CASTER_K_GENERATE);
-      hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1);
+      if (S.integrator == IT_LT)  // walks the first camera connection: one stack per wavefront of the shade grid
+        hipLaunchKernelGGL(k_generate_lt, dim3(r->shade_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1,
+                           r->acc, ln.aux);
+      else
+        hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1);
     }
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, total);
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
@@ -617,9 +622,11 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
       if (S.integrator == IT_AO) hipLaunchKernelGGL(k_shade_ao, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
       else if (S.integrator == IT_VPT)
         hipLaunchKernelGGL(k_shade_vpt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage, ln.aux);
+      else if (S.integrator == IT_LT)
+        hipLaunchKernelGGL(k_shade_lt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage, ln.aux, r->acc);
       else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
     }
-    if (S.integrator != IT_VPT) {
+    if (S.integrator != IT_VPT && S.integrator != IT_LT) {
       {
         ScopedTimer t(r, st, CASTER_K_SHADOW);
         hipLaunchKernelGGL(k_trace<true>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.shadow, aux_for(1));
@@ -645,8 +652,8 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
     HIPCHECK(hipGetLastError());
     return CASTER_OK;
   }
-  if (S.integrator == IT_VPT) {
-    // Boundary crossings do not consume a bounce (pathtracer.cu:1106-1113), so
+  if (S.integrator == IT_VPT || S.integrator == IT_LT) {
+    // Boundary crossings do not consume a bounce (pathtracer.cu:1106-1113, :1318-1325), so
     // the number of rounds is data dependent: after maxDepth rounds keep going
     // while the queue is non-empty.
     int b = ln.batch_b;
@@ -661,6 +668,13 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
     }
   }
   if (failed) return fail(CASTER_ERR_DEVICE, "reading a queue length failed");
+  if (S.integrator == IT_LT) {
+    // light paths have splatted their contributions into the film as they went (float atomics,
+    // from every stream at once): there is no per-pixel colour to add, and a read-modify-write
+    // pass over the film would race with the other streams' splats
+    HIPCHECK(hipGetLastError());
+    return CASTER_OK;
+  }
   // a pixel's samples are added in iteration order whatever stream traced them
   if (r->last_finish && r->last_finish != ln.finish_done) HIPCHECK(hipStreamWaitEvent(st, r->last_finish, 0));
   {
@@ -917,8 +931,12 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   hipStream_t st = ln.stream;
   LaunchCtx L = ctx_of(r, ln);
   const uint32_t total = (uint32_t)r->S.slots_per_iter;
-  hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, st, L, ln.ext[0], iter, 1u,
-                     0, r->S.height);
+  if (r->S.integrator == IT_LT)  // the first surface each light path reaches
+    hipLaunchKernelGGL(k_generate_lt, dim3(r->shade_grid), dim3(kWave), 0, st, L, ln.ext[0], iter, 1u, 0, r->S.height,
+                       (float*)nullptr, ln.aux);
+  else
+    hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, st, L, ln.ext[0], iter, 1u,
+                       0, r->S.height);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, total);
   auto reset_work = [&]() {
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr,

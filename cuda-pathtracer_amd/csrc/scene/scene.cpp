@@ -304,8 +304,9 @@ bool load_impl(const char* filename, Scene& scene, std::string& err, BvhBuilder 
     if (integ == "ao") { scene.integrator = IT_AO; scene.maxDist = optf(doc, "maxDist", 0.5f); }
     else if (integ == "pt") { scene.integrator = IT_PT; scene.maxDepth = opti(doc, "maxDepth", 5); }
     else if (integ == "vpt") { scene.integrator = IT_VPT; scene.maxDepth = opti(doc, "maxDepth", 5); }
+    else if (integ == "lt") { scene.integrator = IT_LT; scene.maxDepth = opti(doc, "maxDepth", 5); }
     else {
-      err = "Unsupport integrator [" + integ + "]: this renderer implements ao, pt and vpt";
+      err = "Unsupport integrator [" + integ + "]: this renderer implements ao, pt, vpt and lt";
       return false;
     }
   }

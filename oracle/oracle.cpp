@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE -- not part of the product.
 //
 // CPU oracle: a plain, scalar restatement of the reference's AO / path /
-// volumetric-path integrators and every device function they call.  One
+// volumetric-path / light-tracing integrators and every device function they call.  One
 // function per reference function, each citing the lines it follows
 // (paths relative to CUDA-PathTracer/tracer/).  The reference does not compile
 // and ships no tests, scenes or golden vectors, so parity against it is
@@ -29,6 +29,7 @@
 //     per transmittance ray.
 #include "oracle.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <string>
@@ -701,9 +702,10 @@ inline float Luminance(V3 c) { return dot(c, v3(0.212671f, 0.715160f, 0.072169f)
 inline bool SameHemiSphere(V3 in, V3 out, V3 nor) { return dot(in, nor) * dot(out, nor) > 0; }  // :219
 inline bool IsDelta(int t) { return t == caster::MT_MIRROR || t == caster::MT_DIELECTRIC; }  // material.h:33
 
-// pathtracer.cu:500-698 (TransportMode::Radiance)
+// pathtracer.cu:500-698; `radiance` false is TransportMode::Importance (light paths), which drops
+// the two radiance-scaling factors of refraction (:549-550, :683-684)
 void SampleBSDF(const Ctx& cx, const Material& material, V3 in, V3 nor, V2 uv, V3 dpdu, V3 u, V3& out,
-                V3& fr, float& pdf) {
+                V3& fr, float& pdf, bool radiance = true) {
   switch (material.type) {
     case caster::MT_LAMBERTIAN: {
       V3 n = nor;
@@ -740,7 +742,7 @@ void SampleBSDF(const Ctx& cx, const Material& material, V3 in, V3 nor, V2 uv, V
       if (u.x > fresnel) {
         out = tdir;
         fr = v3(material.specular) / fabsf(dot(out, normal)) * (1.f - fresnel);
-        fr *= eta * eta;
+        if (radiance) fr *= eta * eta;
         pdf = 1.f - fresnel;
       } else {
         out = rdir;
@@ -826,7 +828,7 @@ void SampleBSDF(const Ctx& cx, const Material& material, V3 in, V3 nor, V2 uv, V
         float c = et * dot(out, wh) + ei * dot(in, wh);
         fr = v3(material.specular) * ei * ei * D * G * (1.f - fresnel) * fabsf(dot(in, wh)) *
              fabsf(dot(out, wh)) / (fabsf(dot(out, n)) * fabsf(dot(in, n)) * c * c);
-        fr *= (1.f / (eta * eta));
+        if (radiance) fr *= (1.f / (eta * eta));
         pdf = (1.f - fresnel) * D * fabsf(dot(wh, n)) * et * et * fabsf(dot(out, wh)) / (c * c);
       } else {
         out = rdir;
@@ -1356,6 +1358,165 @@ bool Volpath(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& 
   return true;
 }
 
+// Camera.h:87-118: connects `pos` to the pinhole.  pdf == 0: the camera does not see `pos`
+// (we and raster are then left alone, as in the reference).
+inline void SampleCamera(const Ctx& cx, V3 pos, Ray& ray, float& we, float& pdf, int& raster) {
+  const caster::Camera& c = cx.scene.camera;
+  V3 dir = v3(c.position) - pos;
+  V3 ndir = normalize(dir);
+  ray = Ray(pos, ndir, -1, cx.scene.epsilon, length(dir) - cx.scene.epsilon);
+  V3 negative_dir = -ndir;
+  V3 cndir = v3(dot(negative_dir, v3(c.u)), dot(negative_dir, v3(c.v)), dot(negative_dir, v3(c.w)));  // ToLocal, common.h:136-139
+  if (cndir.z >= 0.f) { pdf = 0; return; }
+  float costheta = dot(cndir, v3(0, 0, -1.f));
+  float scale = -c.distance / cndir.z;
+  cndir *= scale;
+  V2 plane = V2{cndir.x / c.half_w, cndir.y / c.half_h};
+  if (plane.x > 1.f || plane.x < -1.f || plane.y > 1.f || plane.y < -1.f) { pdf = 0; return; }
+  plane = V2{plane.x * 0.5f + 0.5f, plane.y * 0.5f + 0.5f};
+  int x = fps::f2i_(floorf(plane.x * (c.res_x - 1) + 0.5f));
+  int y = fps::f2i_(floorf(plane.y * (c.res_y - 1) + 0.5f));
+  raster = fps::f2i_(y * c.res_x + x);
+  pdf = dot(dir, dir) / costheta;
+  we = c.distance * c.distance / (c.area * costheta * costheta * costheta * costheta);
+}
+
+// Start of a light path (pathtracer.cu:1245-1261): seed, light choice, a point and a cosine
+// distributed direction on the chosen triangle (area.h:19-24, Triangle.h:157-166).  False when
+// no emissive triangle was chosen: the reference indexes kernel_lights with whatever
+// LookUpLightDistribution returned, which is out of bounds for a scene without emitters and for
+// the environment's bin; such a path draws its five numbers and carries nothing.
+inline bool LightStart(const Ctx& cx, uint32_t pixel, uint32_t iter, Rng& rng, Ray& ray, V3& beta, V3& radiance) {
+  beta = v3(1.f, 1.f, 1.f);
+  float choicePdf;
+  int lightIdx = LookUpLightDistribution(cx, rng.uniform(), choicePdf);
+  V4 u;
+  u.x = rng.uniform(); u.y = rng.uniform(); u.z = rng.uniform(); u.w = rng.uniform();
+  if (lightIdx >= (int)cx.scene.lights.size()) return false;
+  const caster::Light& light = cx.scene.lights[lightIdx];
+  const Prim& p = cx.scene.prims[light.prim];
+  V2 uv = UniformSampleTriangle(u.x, u.y);
+  V3 pos = uv.x * v3(p.v[0].v) + uv.y * v3(p.v[1].v) + (1 - uv.x - uv.y) * v3(p.v[2].v);
+  V3 nor = normalize(uv.x * v3(p.v[0].n) + uv.y * v3(p.v[1].n) + (1 - uv.x - uv.y) * v3(p.v[2].n));
+  float pdfW;
+  V3 dir = CosineSampleHemiSphere(u.z, u.w, pdfW);
+  V3 uu, ww;
+  MakeCoordinate(nor, uu, ww);
+  dir = ToWorld(dir, uu, ww, nor);
+  float pdfA = 1.f / TriArea(p);
+  radiance = v3(light.radiance);
+  ray = Ray(pos, dir, light.medium, cx.scene.epsilon);
+  beta *= radiance * fabsf(dot(ray.dir, nor)) / (pdfA * pdfW * choicePdf);
+  return true;
+}
+
+// pathtracer.cu:1240-1375.  `color` is the iteration's splat buffer (kernel_color, cleared by
+// LightTracingInit :1232-1238); every splat is a plain add here, where the reference uses atomics
+// for all but the first one (:1271, a data race between threads that share a raster position).
+// A connection the camera cannot see (cameraPdf == 0) adds nothing: at :1297-1303 the reference
+// divides uninitialised values by zero and discards the non-finite result.
+void LightTracing(const Ctx& cx, uint32_t pixel, uint32_t iter, float* color, Counters& k) {
+  Rng rng(SampleSeed(pixel, iter));
+  k.c.samples++;
+  const int maxDepth = cx.scene.maxDepth;
+  V3 beta, radiance;
+  Ray ray;
+  if (!LightStart(cx, pixel, iter, rng, ray, beta, radiance)) return;
+  auto splat = [&](int raster, V3 L) {
+    if (raster < 0 || raster >= cx.scene.width * cx.scene.height) return;  // a NaN position
+    color[3 * raster] += L.x; color[3 * raster + 1] += L.y; color[3 * raster + 2] += L.z;
+  };
+  {
+    Ray shadowRay;
+    float we = 0.f, cameraPdf = 0.f;
+    int raster = 0;
+    SampleCamera(cx, ray.origin, shadowRay, we, cameraPdf, raster);
+    shadowRay.medium = ray.medium;
+    if (cameraPdf != 0.f) {
+      V3 tr = Tr(cx, shadowRay, rng, k);
+      if (!IsBlack(tr)) splat(raster, tr * radiance);
+    }
+  }
+  Isect isect;
+  int crossings = 0;
+  for (int bounces = 0; bounces < maxDepth; ++bounces) {
+    if (!Intersect(cx, ray, &isect, k, RK_EXT)) break;
+    k.c.bounces++;
+    V3 pos = isect.pos;
+    V3 nor = isect.n;
+    V2 uv = isect.uv;
+    float sampledDist = 0.f;
+    bool sampledMedium = false;
+    if (ray.medium != -1) beta *= MediumSample(cx.scene.media[ray.medium], ray, rng, sampledDist, sampledMedium);
+    if (IsBlack(beta)) break;
+    if (sampledMedium) {
+      const caster::Medium& med = cx.scene.media[ray.medium];
+      V3 samplePos = ray.at(sampledDist);
+      Ray shadowRay;
+      float we = 0.f, cameraPdf = 0.f;
+      int raster = 0;
+      SampleCamera(cx, samplePos, shadowRay, we, cameraPdf, raster);
+      shadowRay.medium = ray.medium;
+      // Tr() draws random numbers only inside a density grid: without one, a connection that
+      // cannot contribute skips the walk (that changes the ray count only)
+      if (cameraPdf != 0.f || cx.scene.has_heterogeneous) {
+        V3 tr = Tr(cx, shadowRay, rng, k);
+        float phase, unuse;
+        Phase(med, -ray.dir, shadowRay.dir, phase, unuse);
+        if (cameraPdf != 0.f) {
+          V3 L = beta * we * tr * phase / cameraPdf;
+          if (!IsInf(L) && !IsNan(L)) splat(raster, L);
+        }
+      }
+      float phase, pdf;
+      V2 phaseU;
+      phaseU.x = rng.uniform(); phaseU.y = rng.uniform();
+      V3 dir;
+      SamplePhase(med, phaseU, dir, phase, pdf);
+      ray = Ray(samplePos, dir, ray.medium, cx.scene.epsilon);
+    } else {
+      if (isect.matIdx == -1) {
+        if (++crossings > kMaxCrossings) break;
+        bounces--;
+        int m = MediumBySide(dot(ray.dir, isect.n), isect);
+        ray = Ray(pos, ray.dir, m, cx.scene.epsilon);
+        continue;
+      }
+      const Material& mat = cx.scene.materials[isect.matIdx];
+      if (!IsDelta(mat.type)) {
+        Ray shadowRay;
+        float we = 0.f, cameraPdf = 0.f;
+        int raster = 0;
+        SampleCamera(cx, pos, shadowRay, we, cameraPdf, raster);
+        shadowRay.medium = ray.medium;
+        if (cameraPdf != 0.f) {
+          V3 tr = Tr(cx, shadowRay, rng, k);
+          V3 fr;
+          float unuse;
+          Fr(cx, mat, -ray.dir, shadowRay.dir, nor, uv, isect.dpdu, fr, unuse);
+          V3 L = tr * beta * fr * we * fabsf(dot(shadowRay.dir, nor)) / cameraPdf;
+          if (!IsInf(L) && !IsNan(L)) splat(raster, L);
+        }
+      }
+      V3 u;
+      u.x = rng.uniform(); u.y = rng.uniform(); u.z = rng.uniform();
+      V3 out, fr;
+      float pdf;
+      SampleBSDF(cx, mat, -ray.dir, nor, uv, isect.dpdu, u, out, fr, pdf, false);
+      if (IsBlack(fr)) break;
+      beta *= fr * fabsf(dot(out, nor)) / pdf;
+      int m = dot(out, nor) > 0 ? isect.mediumOutside : isect.mediumInside;
+      m = dot(-ray.dir, nor) * dot(out, nor) > 0 ? ray.medium : m;
+      ray = Ray(pos, out, m, cx.scene.epsilon);
+    }
+    if (bounces > 3) {
+      float illumate = fps::clamp_(1.f - Luminance(beta), 0.f, 1.f);
+      if (rng.uniform() < illumate) break;
+      beta /= (1 - illumate);
+    }
+  }
+}
+
 inline bool Sample(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& k) {
   switch (cx.scene.integrator) {
     case caster::IT_AO: return Ao(cx, pixel, iter, color, k);
@@ -1413,8 +1574,38 @@ int oracle_render_rows(oracle_ctx* c, uint32_t first_iter, uint32_t n_iter, int 
   if (y0 < 0 || y1 > cx.scene.height || y0 > y1) return 1;
   const uint32_t H = (uint32_t)y1;
   if (threads <= 0) threads = 1;
-  std::atomic<uint32_t> next_row{(uint32_t)y0};
   std::vector<Counters> ks(threads);
+  if (cx.scene.integrator == caster::IT_LT) {
+    // Light paths splat anywhere on the film: rows [y0, y1) select which paths are traced, not
+    // where they land.  Each thread takes a fixed share of the rows and splats into a buffer of
+    // its own; per iteration the buffers are summed in thread order (kernel_color) and added to
+    // acc as Output() does (pathtracer.cu:2502-2513), so the result depends on `threads` only
+    // in the rounding of those sums.
+    const size_t n3 = (size_t)W * cx.scene.height * 3;
+    std::vector<std::vector<float>> color(threads, std::vector<float>(n3));
+    for (uint32_t it = 0; it < n_iter; ++it) {
+      auto work = [&](int tid) {
+        std::fill(color[tid].begin(), color[tid].end(), 0.f);
+        uint32_t rows = H - (uint32_t)y0;
+        uint32_t r0 = (uint32_t)y0 + (uint32_t)((uint64_t)rows * tid / threads);
+        uint32_t r1 = (uint32_t)y0 + (uint32_t)((uint64_t)rows * (tid + 1) / threads);
+        for (uint32_t y = r0; y < r1; ++y)
+          for (uint32_t x = 0; x < W; ++x) LightTracing(cx, x + y * W, first_iter + it, color[tid].data(), ks[tid]);
+      };
+      std::vector<std::thread> pool;
+      for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+      work(0);
+      for (auto& t : pool) t.join();
+      for (size_t i = 0; i < n3; ++i) {
+        float c = color[0][i];
+        for (int t = 1; t < threads; ++t) c += color[t][i];
+        acc[i] += c;
+      }
+    }
+    if (counts) for (auto& k : ks) add_counts(counts, k.c);
+    return 0;
+  }
+  std::atomic<uint32_t> next_row{(uint32_t)y0};
   auto work = [&](int tid) {
     Counters& k = ks[tid];
     for (;;) {
@@ -1461,9 +1652,15 @@ int oracle_primary_ids(oracle_ctx* c, uint32_t iter, int32_t* ids) {
   uint32_t n = (uint32_t)cx.scene.width * cx.scene.height;
   for (uint32_t p = 0; p < n; ++p) {
     Rng rng(SampleSeed(p, iter));
+    Isect is;
+    if (cx.scene.integrator == caster::IT_LT) {  // the first surface the light path of (p, iter) reaches
+      V3 beta, radiance;
+      Ray ray;
+      ids[p] = LightStart(cx, p, iter, rng, ray, beta, radiance) && Intersect(cx, ray, &is, k, RK_EXT) ? is.prim : -1;
+      continue;
+    }
     Ray ray = CameraSample(cx, p, iter, rng);
     if (cx.scene.integrator == caster::IT_VPT) ray.medium = cx.scene.camera.medium;
-    Isect is;
     ids[p] = Intersect(cx, ray, &is, k, RK_EXT) ? is.prim : -1;
   }
   return 0;
@@ -1539,6 +1736,14 @@ int oracle_occluded(const oracle_ctx* c, const float* o, const float* d, float t
   Counters k;
   Ray r(v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), -1, tmin, tmax);
   return IntersectPrimitive(c->cx, r, k, RK_SHADOW) ? 1 : 0;
+}
+int oracle_sample_camera(const oracle_ctx* c, const float* pos, float* out) {
+  Ray ray;
+  float we = 0.f, pdf = 0.f;
+  int raster = -1;
+  SampleCamera(c->cx, v3(pos[0], pos[1], pos[2]), ray, we, pdf, raster);
+  out[0] = we; out[1] = pdf; out[2] = ray.tmax;
+  return pdf != 0.f ? raster : -1;
 }
 void oracle_bsdf_sample(const oracle_ctx* c, int mat, const float* wo, const float* n, const float* dpdu,
                         const float* uv, const float* u3, float* o) {

@@ -27,6 +27,9 @@ SMALL_SCENES = {
     "cornell_vpt": dict(name="cornell_vpt", width=96, height=96, depth=8),
     "cornell_meshlight": dict(name="cornell_meshlight", width=96, height=96),
     "cornell_smoke": dict(name="cornell_smoke", width=96, height=96, depth=8),
+    "cornell_lt": dict(name="cornell_lt", width=96, height=96),
+    "cornell_fog_lt": dict(name="cornell_fog_lt", width=96, height=96, depth=8),
+    "cornell_smoke_lt": dict(name="cornell_smoke_lt", width=96, height=96, depth=8),
     "knot_pt": dict(name="knot_pt", width=96, height=96, detail=0.08),
     "stairs_pt": dict(name="stairs_pt", width=128, height=72, detail=0.08),
     "car_pt": dict(name="car_pt", width=128, height=72, detail=0.01),

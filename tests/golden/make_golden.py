@@ -30,6 +30,12 @@ SCENES = {
     "car_env": dict(name="car_pt", width=80, height=48, detail=0.004, env=True),
 }
 SPP = 8
+# Light tracing: a film and a first-hit map only (the per-function vectors above are those of the
+# camera-side integrators).  The film's rounding depends on the oracle's thread count: fixed at 4.
+LT_SCENES = {
+    "cornell_fog_lt": dict(name="cornell_fog_lt", width=64, height=64, depth=8),
+}
+LT_SPP, LT_THREADS = 4, 4
 
 
 def f32list(a):
@@ -88,7 +94,28 @@ def main():
         print(key, "mean", acc.mean() / SPP)
     with open(os.path.join(HERE, "vectors.json"), "w") as f:
         json.dump(vec, f, indent=0)
+    make_light_tracing()
+
+
+def make_light_tracing():
+    out = {}
+    for key, kw in LT_SCENES.items():
+        kw = dict(kw)
+        name = kw.pop("name")
+        path = gen_scenes.generate(os.path.join(HERE, "scenes", key), name, **kw)
+        o = ol.Oracle(path)
+        c = ol.Counts()
+        acc = o.render(1, LT_SPP, LT_THREADS, counts=c)
+        np.save(os.path.join(HERE, key + "_sum.npy"), acc)
+        np.save(os.path.join(HERE, key + "_ids.npy"), o.primary_ids(1))
+        out[key] = {"spp": LT_SPP, "threads": LT_THREADS, "counts": c.as_dict()}
+        print(key, "mean", acc.mean() / LT_SPP)
+    with open(os.path.join(HERE, "light_tracing.json"), "w") as f:
+        json.dump(out, f, indent=0)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["lt"]:   # only the light-tracing fixtures
+        make_light_tracing()
+    else:
+        main()

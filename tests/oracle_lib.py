@@ -53,6 +53,7 @@ def lib():
         L.oracle_camera_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, fp]
         L.oracle_trace.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float, fp]
         L.oracle_occluded.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float]
+        L.oracle_sample_camera.argtypes = [C.c_void_p, fp, fp]
         L.oracle_bsdf_sample.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, fp, fp]
         L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, fp, fp]
         L.oracle_light_sample.argtypes = [C.c_void_p, C.c_int, fp, fp, fp]
@@ -129,6 +130,12 @@ class Oracle:
 
     def occluded(self, origin, direction, tmin=1e-3, tmax=np.inf):
         return bool(self.L.oracle_occluded(self.h, _fp(_f32(origin)), _fp(_f32(direction)), tmin, tmax))
+
+    def sample_camera(self, pos):
+        """(raster index or -1, [importance, pdf, tmax])"""
+        o = np.zeros(3, np.float32)
+        raster = self.L.oracle_sample_camera(self.h, _fp(_f32(pos)), _fp(o))
+        return raster, o
 
     def bsdf_sample(self, mat, wo, n, dpdu, uv, u3):
         o = np.zeros(7, np.float32)
