@@ -247,7 +247,7 @@ def main():
         # The dominant kernel is the one with the largest total time in the timed region.  With
         # several streams a launch shares the GPU with the other streams' kernels while it runs, so
         # `exclusive` repeats the measurement on one stream (same batch size), after the timed region.
-        shade_name = {0: "k_shade_ao", 1: "k_shade_pt", 2: "k_shade_vpt"}[scene.integrator]
+        shade_name = {0: "k_shade_ao", 1: "k_shade_pt", 2: "k_shade_vpt", 3: "k_shade_lt", 4: "k_bdpt"}[scene.integrator]
         symbols = {"k_trace<false>": (("extend", 0), ("probe", 2)), "k_trace<true>": (("shadow", 1),),
                    shade_name: (("shade", None),)}
 

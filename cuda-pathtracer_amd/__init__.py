@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CASTER_LIB") or os.path.join(_HERE, "libcaster.so")
 
 IT_AO, IT_PT, IT_VPT = 0, 1, 2
-INTEGRATOR_NAMES = {0: "ao", 1: "pt", 2: "vpt", 3: "lt"}
+INTEGRATOR_NAMES = {0: "ao", 1: "pt", 2: "vpt", 3: "lt", 4: "bdpt"}
 
 
 class CasterError(RuntimeError):

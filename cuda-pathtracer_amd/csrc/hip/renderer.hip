@@ -278,6 +278,7 @@ struct Lane {
   uint32_t* counters = nullptr;  // queue lengths: ext0, ext1, shadow, probe, tr1; then 3 x kWorkShards work counters
   WalkAux aux{};
   StageArea stage{};
+  BdptStore bdpt{};  // sub-path vertices of the bidirectional integrator, one column per lane of its grid
   Stats* stats = nullptr;
   hipEvent_t finish_done = nullptr;  // recorded after the lane's latest k_finish
   // batch under way between the two halves of its submission
@@ -295,6 +296,7 @@ struct caster_renderer {
   uint32_t work_init = 0;
   int walk_grid = 0;
   int shade_grid = 0;
+  int bdpt_grid = 0;  // workgroups of k_bdpt (one sample per lane at a time)
   bool vpt_queues = false;  // volumetric integrator with its shadow and probe rays on queues (no density grid in the scene)
   float* acc = nullptr;
   float* film_tmp = nullptr;
@@ -348,7 +350,8 @@ static int alloc_queue(caster_renderer* r, RayQueue& q, uint32_t n, bool with_hi
 
 static int alloc_lane(caster_renderer* r, Lane& ln) {
   int rc;
-  const uint32_t n = r->pool_slots;
+  // the bidirectional integrator keeps no paths in queues: its queues only serve the first-hit map
+  const uint32_t n = r->S.integrator == IT_BDPT ? (uint32_t)r->S.slots_per_iter : r->pool_slots;
   HIPCHECK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreateWithFlags(&ln.finish_done, hipEventDisableTiming));
   if ((rc = dev_alloc(r, &ln.P.beta_rng, n))) return rc;
@@ -379,6 +382,10 @@ static int alloc_lane(caster_renderer* r, Lane& ln) {
   ln.aux.spill_stride = (uint32_t)r->walk_grid * kWave;
   if ((rc = dev_alloc(r, &ln.aux.spill, (size_t)ln.aux.spill_stride * kSpillDepth))) return rc;
   ln.aux.work = ln.counters + 64;
+  if (r->S.integrator == IT_BDPT) {
+    ln.bdpt.stride = (uint32_t)r->bdpt_grid * kWave;
+    if ((rc = dev_alloc(r, &ln.bdpt.v, (size_t)kBdptVertF4 * 2 * kBdptPathVerts * ln.bdpt.stride))) return rc;
+  }
   if ((rc = dev_alloc(r, &ln.stats, 1))) return rc;
   HIPCHECK(hipMemset(ln.stats, 0, sizeof(Stats)));
   return CASTER_OK;
@@ -492,6 +499,13 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     r->walk_grid = r->n_cu * std::max(kTraceBlockWaves, std::min(by_lds, by_regs));
   }
   r->work_init = ((uint32_t)r->walk_grid + kWorkShards - 1) / kWorkShards * kChunk;
+  if (sc.integrator == IT_BDPT) {
+    // one sample per lane at a time: as many wavefronts as are resident at once, within the
+    // traversal grid (whose stack spill columns k_bdpt's lanes use)
+    int per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_bdpt, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    r->bdpt_grid = std::min(r->n_cu * std::min(per_cu, 16), r->walk_grid);
+  }
   r->lanes.resize((size_t)n_streams);
   for (Lane& ln : r->lanes)
     if ((rc = alloc_lane(r, ln))) return rc;
@@ -553,6 +567,17 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
   const int shade_grid = r->shade_grid;
   const int gen_grid = (int)std::min<uint32_t>((total + kWave - 1) / kWave, (uint32_t)r->n_cu * 32);
   int cur = tail ? ln.batch_cur : 0;
+  if (S.integrator == IT_BDPT) {
+    // the whole sample runs in one kernel and splats into the film with float atomics (from every
+    // stream at once, as light tracing does): nothing to submit in the second half
+    if (!tail) {
+      ScopedTimer t(r, st, CASTER_K_SHADE);
+      hipLaunchKernelGGL(k_bdpt, dim3(r->bdpt_grid), dim3(kWave), 0, st, L, first, n, r->y0, r->y1, r->acc, ln.aux, ln.bdpt);
+      ln.batch_first = first; ln.batch_n = n;
+    }
+    HIPCHECK(hipGetLastError());
+    return CASTER_OK;
+  }
   if (!tail) {
     {
       ScopedTimer t(r, st, CASTER_K_GENERATE);

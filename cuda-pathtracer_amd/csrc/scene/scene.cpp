@@ -305,8 +305,9 @@ bool load_impl(const char* filename, Scene& scene, std::string& err, BvhBuilder 
     else if (integ == "pt") { scene.integrator = IT_PT; scene.maxDepth = opti(doc, "maxDepth", 5); }
     else if (integ == "vpt") { scene.integrator = IT_VPT; scene.maxDepth = opti(doc, "maxDepth", 5); }
     else if (integ == "lt") { scene.integrator = IT_LT; scene.maxDepth = opti(doc, "maxDepth", 5); }
+    else if (integ == "bdpt") { scene.integrator = IT_BDPT; scene.maxDepth = opti(doc, "maxDepth", 5); }
     else {
-      err = "Unsupport integrator [" + integ + "]: this renderer implements ao, pt, vpt and lt";
+      err = "Unsupport integrator [" + integ + "]: this renderer implements ao, pt, vpt, lt and bdpt";
       return false;
     }
   }

@@ -1517,6 +1517,399 @@ void LightTracing(const Ctx& cx, uint32_t pixel, uint32_t iter, float* color, Co
   }
 }
 
+// ------------------------------------------------------------------- BDPT
+// pathtracer.cu:1379-1956.  Conventions fixed here (mirrored by the HIP renderer):
+//   * fwd/rev of a vertex are read by MisWeight only after they were written (checked below
+//     for every (s, t)); they start at zero instead of the reference's uninitialised memory;
+//   * a light choice that is not an emissive triangle (no emitters, or the environment's bin,
+//     where the reference reads past kernel_lights) gives an empty light path, and a t == 1
+//     connection to such a choice draws its three numbers and adds nothing;
+//   * at most kMaxCrossings index-matched boundary crossings per sub-path;
+//   * maxDepth is not used (the reference's kernel ignores it, :1919-1956): sub-paths end by
+//     Russian roulette or after BDPT_MAX_DEPTH bounces.
+const int kBdptMaxDepth = 65;  // BDPT_MAX_DEPTH, :1379
+
+struct BdptVertex {  // :1381-1388
+  V3 beta{0, 0, 0};
+  Isect isect;
+  int medium = -1;
+  bool delta = false;
+  float fwd = 0.f, rev = 0.f;
+};
+
+// Camera.h:121-126
+inline void PdfCamera(const caster::Camera& c, V3 dir, float& pdfA, float& pdfW) {
+  pdfA = 1.f;
+  float costheta = dot(dir, -v3(c.w));
+  pdfW = c.distance * c.distance / (c.area * costheta * costheta * costheta);
+}
+
+// :1391-1399
+inline float ConvertPdf(float pdf, const Isect& prev, const Isect& cur) {
+  V3 dir = prev.pos - cur.pos;
+  float square = dot(dir, dir);
+  dir = normalize(dir);
+  float ret = pdf / square;
+  if (!IsBlack(cur.n)) ret *= fabsf(dot(dir, cur.n));
+  return ret;
+}
+
+// The walk shared by GenerateCameraPath (:1431-1534) and GenerateLightPath (:1569-1671): the two
+// loops differ in the transport mode of SampleBSDF only.  path[0] is set by the caller.
+int BdptWalk(const Ctx& cx, Ray ray, V3 beta, float forward, bool radiance, BdptVertex* path, Rng& rng, Counters& k) {
+  int nVertex = 1;
+  Isect isect;
+  int crossings = 0;
+  for (int bounces = 0; bounces < kBdptMaxDepth; ++bounces) {
+    if (!Intersect(cx, ray, &isect, k, RK_EXT)) break;
+    k.c.bounces++;
+    V3 pos = isect.pos;
+    V3 nor = isect.n;
+    V2 uv = isect.uv;
+    float sampledDist = 0.f;
+    bool sampledMedium = false;
+    if (ray.medium != -1) beta *= MediumSample(cx.scene.media[ray.medium], ray, rng, sampledDist, sampledMedium);
+    if (IsBlack(beta)) break;
+    if (sampledMedium) {
+      const caster::Medium& med = cx.scene.media[ray.medium];
+      V3 samplePos = ray.at(sampledDist);
+      float phase, pdf;
+      V2 phaseU;
+      phaseU.x = rng.uniform(); phaseU.y = rng.uniform();
+      V3 dir;
+      SamplePhase(med, phaseU, dir, phase, pdf);
+      ray = Ray(samplePos, dir, ray.medium, cx.scene.epsilon);
+      BdptVertex vertex;
+      vertex.isect.pos = samplePos;
+      vertex.isect.n = v3(0.f, 0.f, 0.f);
+      vertex.isect.matIdx = -1;
+      vertex.isect.lightIdx = -1;
+      vertex.beta = beta;
+      vertex.delta = false;
+      vertex.medium = ray.medium;
+      path[bounces + 1] = vertex;
+      path[bounces + 1].fwd = ConvertPdf(forward, path[bounces].isect, path[bounces + 1].isect);
+      forward = phase;
+      path[bounces].rev = ConvertPdf(forward, path[bounces + 1].isect, path[bounces].isect);
+      nVertex++;
+    } else {
+      if (isect.matIdx == -1) {
+        if (++crossings > kMaxCrossings) break;
+        bounces--;
+        int m = MediumBySide(dot(ray.dir, isect.n), isect);
+        ray = Ray(pos, ray.dir, m, cx.scene.epsilon);
+        continue;
+      }
+      const Material& mat = cx.scene.materials[isect.matIdx];
+      {
+        BdptVertex vertex;
+        vertex.beta = beta;
+        vertex.isect = isect;
+        vertex.delta = IsDelta(mat.type);
+        vertex.medium = ray.medium;
+        path[bounces + 1] = vertex;
+        path[bounces + 1].fwd = ConvertPdf(forward, path[bounces].isect, path[bounces + 1].isect);
+      }
+      nVertex++;
+      V3 u;
+      u.x = rng.uniform(); u.y = rng.uniform(); u.z = rng.uniform();
+      V3 out, fr;
+      float pdf;
+      SampleBSDF(cx, mat, -ray.dir, nor, uv, isect.dpdu, u, out, fr, pdf, radiance);
+      if (IsBlack(fr)) break;
+      beta *= fr * fabsf(dot(out, nor)) / pdf;
+      forward = pdf;
+      if (IsDelta(mat.type)) forward = 0.f;
+      {
+        V3 unuseFr;
+        float rpdf;
+        Fr(cx, mat, out, -ray.dir, nor, uv, isect.dpdu, unuseFr, rpdf);
+        path[bounces].rev = ConvertPdf(rpdf, path[bounces + 1].isect, path[bounces].isect);
+      }
+      int m = dot(out, nor) > 0 ? isect.mediumOutside : isect.mediumInside;
+      m = dot(-ray.dir, nor) * dot(out, nor) > 0 ? ray.medium : m;
+      ray = Ray(pos, out, m, cx.scene.epsilon);
+    }
+    if (bounces > 3) {
+      float rrPdf = fps::clamp_(1.f - Luminance(beta), 0.f, 1.f);
+      if (rng.uniform() < rrPdf) break;
+      beta /= (1 - rrPdf);
+    }
+  }
+  return nVertex;
+}
+
+// The camera ray of a BDPT sample (:1403-1410): two jitter draws, no lens sample.
+inline Ray BdptCameraRay(const Ctx& cx, uint32_t pixel, Rng& rng) {
+  uint32_t W = (uint32_t)cx.scene.width;
+  uint32_t x = pixel % W, y = pixel / W;
+  float offsetx = rng.uniform() - 0.5f;
+  float offsety = rng.uniform() - 0.5f;
+  Ray ray = GeneratePrimaryRay(cx.scene.camera, x + offsetx, y + offsety, V2{0.f, 0.f});
+  ray.tmin = cx.scene.epsilon;
+  ray.medium = cx.scene.camera.medium;
+  return ray;
+}
+
+// :1401-1537
+int GenerateCameraPath(const Ctx& cx, uint32_t pixel, BdptVertex* path, Rng& rng, Counters& k) {
+  Ray ray = BdptCameraRay(cx, pixel, rng);
+  BdptVertex vertex;
+  vertex.isect.pos = v3(cx.scene.camera.position);
+  vertex.isect.n = -v3(cx.scene.camera.w);
+  vertex.beta = v3(1.f, 1.f, 1.f);
+  vertex.delta = false;
+  vertex.medium = ray.medium;
+  vertex.fwd = 1.f;
+  path[0] = vertex;
+  float forward = 0.f, unuse;
+  PdfCamera(cx.scene.camera, ray.dir, unuse, forward);
+  return BdptWalk(cx, ray, v3(1.f, 1.f, 1.f), forward, true, path, rng, k);
+}
+
+// :1539-1674
+int GenerateLightPath(const Ctx& cx, BdptVertex* path, Rng& rng, Counters& k) {
+  float choicePdf;
+  int lightIdx = LookUpLightDistribution(cx, rng.uniform(), choicePdf);
+  V4 u;
+  u.x = rng.uniform(); u.y = rng.uniform(); u.z = rng.uniform(); u.w = rng.uniform();
+  if (lightIdx >= (int)cx.scene.lights.size()) return 0;
+  const caster::Light& light = cx.scene.lights[lightIdx];
+  const Prim& p = cx.scene.prims[light.prim];
+  // Area::SampleLight(u, ...) (area.h:19-24) = Triangle::SampleShape (Triangle.h:157-166)
+  V2 uv = UniformSampleTriangle(u.x, u.y);
+  V3 pos = uv.x * v3(p.v[0].v) + uv.y * v3(p.v[1].v) + (1 - uv.x - uv.y) * v3(p.v[2].v);
+  V3 lightNor = normalize(uv.x * v3(p.v[0].n) + uv.y * v3(p.v[1].n) + (1 - uv.x - uv.y) * v3(p.v[2].n));
+  float pdfW;
+  V3 dir = CosineSampleHemiSphere(u.z, u.w, pdfW);
+  V3 uu, ww;
+  MakeCoordinate(lightNor, uu, ww);
+  dir = ToWorld(dir, uu, ww, lightNor);
+  float pdfA = 1.f / TriArea(p);
+  V3 radiance = v3(light.radiance);
+  Ray ray(pos, dir, light.medium, cx.scene.epsilon);
+  BdptVertex vertex;
+  vertex.isect.pos = ray.origin;
+  vertex.isect.n = lightNor;
+  vertex.isect.lightIdx = lightIdx;
+  vertex.beta = radiance;
+  vertex.delta = false;
+  vertex.medium = ray.medium;
+  vertex.fwd = pdfA * choicePdf;
+  path[0] = vertex;
+  V3 beta = v3(1.f, 1.f, 1.f);
+  beta *= radiance * fabsf(dot(ray.dir, lightNor)) / (pdfA * pdfW * choicePdf);
+  return BdptWalk(cx, ray, beta, pdfW, false, path, rng, k);
+}
+
+// :1676-1704
+float MisWeight(const BdptVertex* cameraPath, const BdptVertex* lightPath, int s, int t) {
+  if (s + t == 2) return 1.f;
+  auto remap = [](float pdf) -> float { return pdf == 0 ? 1.f : pdf; };
+  float sumW = 0.f;
+  float ri = 1.f;
+  for (int i = s - 1; i > 0; --i) {
+    ri *= remap(cameraPath[i].rev) / remap(cameraPath[i].fwd);
+    if (!cameraPath[i].delta && !cameraPath[i - 1].delta) sumW += ri;
+  }
+  ri = 1.f;
+  for (int i = t - 1; i >= 0; --i) {
+    ri *= remap(lightPath[i].rev) / remap(lightPath[i].fwd);
+    bool delta = lightPath[i == 0 ? 0 : i - 1].delta;
+    if (!lightPath[i].delta && !delta) sumW += ri;
+  }
+  return 1.f / (sumW + 1.f);
+}
+
+// Phase function or BSDF of a sub-path vertex, as Connect() picks between them.
+inline void VertexFr(const Ctx& cx, bool useMedium, const BdptVertex& v, const Material* mat, V3 in, V3 out, V3& fr,
+                     float& pdf) {
+  if (useMedium) {
+    float phase;
+    Phase(cx.scene.media[v.medium], in, out, phase, pdf);
+    fr = v3(phase, phase, phase);
+  } else {
+    Fr(cx, *mat, in, out, v.isect.n, v.isect.uv, v.isect.dpdu, fr, pdf);
+  }
+}
+
+// :1706-1909
+V3 Connect(const Ctx& cx, BdptVertex* cameraPath, BdptVertex* lightPath, int s, int t, int& raster, Rng& rng,
+           Counters& k) {
+  const V3 zero = v3(0.f, 0.f, 0.f);
+  V3 L = zero;
+  const float eps = cx.scene.epsilon;
+  if (t == 0) {  // the camera path hit an emitter
+    BdptVertex& cur = cameraPath[s - 1];
+    BdptVertex& prev = cameraPath[s - 2];
+    if (cur.isect.lightIdx == -1) return zero;
+    V3 dir = normalize(prev.isect.pos - cur.isect.pos);
+    L += cur.beta * AreaLe(cx, cur.isect.lightIdx, cur.isect.n, dir);
+    if (IsBlack(L)) return L;
+    float choicePdf = PdfFromLightDistribution(cx, cur.isect.lightIdx);
+    float pdfA, pdfW;
+    AreaPdf(cx, cur.isect.lightIdx, dir, cur.isect.n, pdfA, pdfW);
+    float curRev = cur.rev, prevRev = prev.rev;
+    cur.rev = pdfA * choicePdf;
+    prev.rev = ConvertPdf(pdfW, cur.isect, prev.isect);
+    float mis = MisWeight(cameraPath, lightPath, s, t);
+    cur.rev = curRev;
+    prev.rev = prevRev;
+    return mis * L;
+  } else if (t == 1) {  // next event estimation from the camera path
+    BdptVertex& prev = cameraPath[s - 2];
+    BdptVertex& cur = cameraPath[s - 1];
+    BdptVertex& next = lightPath[0];
+    V3 in = normalize(prev.isect.pos - cur.isect.pos);
+    bool isMedium = cur.isect.matIdx == -1;
+    const Material* mat = isMedium ? nullptr : &cx.scene.materials[cur.isect.matIdx];
+    float choicePdf, lightPdf;
+    int idx = LookUpLightDistribution(cx, rng.uniform(), choicePdf);
+    V2 lightUniform;
+    lightUniform.x = rng.uniform(); lightUniform.y = rng.uniform();
+    if (idx >= (int)cx.scene.lights.size()) return zero;
+    V3 radiance, lightNor, lightPos;
+    Ray shadowRay;
+    AreaSampleLight(cx, idx, cur.isect.pos, lightUniform, radiance, shadowRay, lightNor, lightPdf);
+    lightPos = shadowRay.at(shadowRay.tmax + eps);
+    shadowRay.medium = cur.medium;
+    if (IsBlack(radiance)) return zero;
+    if (!isMedium && IsDelta(mat->type)) return zero;
+    V3 sdir = shadowRay.dir;
+    V3 tr = Tr(cx, shadowRay, rng, k);
+    if (IsBlack(tr)) return zero;
+    V3 fr;
+    float nextPdf, G;
+    VertexFr(cx, isMedium, cur, mat, in, sdir, fr, nextPdf);
+    G = isMedium ? 1.f : fabsf(dot(cur.isect.n, sdir));
+    L += cur.beta * tr * fr * radiance * G / (lightPdf * choicePdf);
+    if (IsBlack(L)) return zero;
+    BdptVertex tNext = next;
+    float pdfA, pdfW;
+    AreaPdf(cx, idx, sdir, lightNor, pdfA, pdfW);
+    next.isect.pos = lightPos;
+    next.isect.n = lightNor;
+    next.fwd = pdfA * choicePdf;
+    next.rev = ConvertPdf(nextPdf, cur.isect, next.isect);
+    float curRev = cur.rev, prevRev = prev.rev;
+    cur.rev = ConvertPdf(pdfW, next.isect, cur.isect);
+    float pdf;
+    VertexFr(cx, isMedium, cur, mat, sdir, in, fr, pdf);
+    prev.rev = ConvertPdf(pdf, cur.isect, prev.isect);
+    float mis = MisWeight(cameraPath, lightPath, s, t);
+    cur.rev = curRev;
+    prev.rev = prevRev;
+    next = tNext;
+    return mis * L;
+  } else if (s == 1) {  // the light path connected to the pinhole
+    BdptVertex& prev = lightPath[t - 2];
+    BdptVertex& cur = lightPath[t - 1];
+    BdptVertex& next = cameraPath[0];
+    V3 in = normalize(prev.isect.pos - cur.isect.pos);
+    bool isMedium = cur.isect.matIdx == -1;
+    const Material* mat = isMedium ? nullptr : &cx.scene.materials[cur.isect.matIdx];
+    Ray shadowRay;
+    float we = 0.f, cameraPdf = 0.f;
+    SampleCamera(cx, cur.isect.pos, shadowRay, we, cameraPdf, raster);
+    shadowRay.medium = cur.medium;
+    if (cameraPdf == 0) return zero;
+    if (!isMedium && IsDelta(mat->type)) return zero;
+    V3 sdir = shadowRay.dir;
+    V3 tr = Tr(cx, shadowRay, rng, k);
+    if (IsBlack(tr)) return zero;
+    V3 fr;
+    float nextPdf, costheta = fabsf(dot(sdir, cur.isect.n));
+    VertexFr(cx, isMedium, cur, mat, in, sdir, fr, nextPdf);
+    if (isMedium) costheta = 1.f;
+    L += cur.beta * tr * fr * we * costheta / cameraPdf;
+    if (IsBlack(L)) return zero;
+    float nextRev = next.rev, curRev = cur.rev, prevRev = prev.rev;
+    next.rev = ConvertPdf(nextPdf, cur.isect, next.isect);
+    float pdfA, pdfW;
+    PdfCamera(cx.scene.camera, -sdir, pdfA, pdfW);
+    cur.rev = ConvertPdf(pdfW, next.isect, cur.isect);
+    float pdf;
+    VertexFr(cx, isMedium, cur, mat, sdir, in, fr, pdf);
+    prev.rev = ConvertPdf(pdf, cur.isect, prev.isect);
+    float mis = MisWeight(cameraPath, lightPath, s, t);
+    next.rev = nextRev;
+    cur.rev = curRev;
+    prev.rev = prevRev;
+    return mis * L;
+  }
+  // an inner vertex of each path joined by a shadow ray.  Here the reference tells a medium
+  // vertex from a surface vertex by the vertex's medium, not by its material (:1854-1881): a
+  // surface reached through a medium is given that medium's phase function.
+  BdptVertex& c2 = cameraPath[s - 2];
+  BdptVertex& c1 = cameraPath[s - 1];
+  BdptVertex& l1 = lightPath[t - 1];
+  BdptVertex& l2 = lightPath[t - 2];
+  V3 l1Tol2 = normalize(l2.isect.pos - l1.isect.pos);
+  V3 l1Toc1 = normalize(c1.isect.pos - l1.isect.pos);
+  V3 c1Tol1 = -l1Toc1;
+  V3 c1Toc2 = normalize(c2.isect.pos - c1.isect.pos);
+  V3 dir = c1.isect.pos - l1.isect.pos;
+  bool c1Med = c1.medium != -1, l1Med = l1.medium != -1;
+  const Material* c1Mat = c1Med ? nullptr : &cx.scene.materials[c1.isect.matIdx];
+  const Material* l1Mat = l1Med ? nullptr : &cx.scene.materials[l1.isect.matIdx];
+  Ray shadowRay;
+  shadowRay.origin = c1.isect.pos;
+  shadowRay.dir = c1Tol1;
+  shadowRay.medium = c1.medium;
+  shadowRay.tmin = eps;
+  shadowRay.tmax = length(dir) - eps;
+  if (!c1Med && IsDelta(c1Mat->type)) return zero;
+  if (!l1Med && IsDelta(l1Mat->type)) return zero;
+  V3 tr = Tr(cx, shadowRay, rng, k);
+  if (IsBlack(tr)) return zero;
+  float cos1 = l1Med ? 1.f : fabsf(dot(l1Toc1, l1.isect.n));
+  float cos2 = c1Med ? 1.f : fabsf(dot(c1Tol1, c1.isect.n));
+  V3 c1Fr, l1Fr;
+  float l1Pdf, c1Pdf;
+  VertexFr(cx, c1Med, c1, c1Mat, c1Toc2, c1Tol1, c1Fr, l1Pdf);
+  VertexFr(cx, l1Med, l1, l1Mat, l1Tol2, l1Toc1, l1Fr, c1Pdf);
+  V3 G = tr * cos1 * cos2 / dot(dir, dir);
+  L += c1.beta * c1Fr * G * l1Fr * l1.beta;
+  if (IsBlack(L)) return zero;
+  float c2Rev = c2.rev, c1Rev = c1.rev, l1Rev = l1.rev, l2Rev = l2.rev;
+  c1.rev = ConvertPdf(c1Pdf, l1.isect, c1.isect);
+  l1.rev = ConvertPdf(l1Pdf, c1.isect, l1.isect);
+  float l2Pdf, c2Pdf;
+  VertexFr(cx, l1Med, l1, l1Mat, l1Toc1, l1Tol2, l1Fr, l2Pdf);
+  VertexFr(cx, c1Med, c1, c1Mat, c1Tol1, c1Toc2, c1Fr, c2Pdf);
+  l2.rev = ConvertPdf(l2Pdf, l1.isect, l2.isect);
+  c2.rev = ConvertPdf(c2Pdf, c1.isect, c2.isect);
+  float mis = MisWeight(cameraPath, lightPath, s, t);
+  c2.rev = c2Rev;
+  c1.rev = c1Rev;
+  l1.rev = l1Rev;
+  l2.rev = l2Rev;
+  return mis * L;
+}
+
+// :1919-1956.  `color` is the iteration's buffer (kernel_color, cleared by BdptInit :1911-1917);
+// the reference's atomic adds are plain adds here.
+void Bdpt(const Ctx& cx, uint32_t pixel, uint32_t iter, float* color, Counters& k) {
+  Rng rng(SampleSeed(pixel, iter));
+  k.c.samples++;
+  BdptVertex cameraPath[kBdptMaxDepth + 2];
+  BdptVertex lightPath[kBdptMaxDepth + 2];
+  int nCamera = GenerateCameraPath(cx, pixel, cameraPath, rng, k);
+  int nLight = GenerateLightPath(cx, lightPath, rng, k);
+  const int nPix = cx.scene.width * cx.scene.height;
+  for (int s = 1; s <= nCamera; ++s) {
+    for (int t = 0; t <= nLight; ++t) {
+      if ((s == 1 && t == 0) || (s == 1 && t == 1)) continue;
+      int raster = -1;
+      V3 L = Connect(cx, cameraPath, lightPath, s, t, raster, rng, k);
+      if (IsInf(L) || IsNan(L) || IsBlack(L)) continue;
+      int where = s == 1 ? raster : (int)pixel;
+      if (where < 0 || where >= nPix) continue;  // a NaN position
+      color[3 * where] += L.x; color[3 * where + 1] += L.y; color[3 * where + 2] += L.z;
+    }
+  }
+}
+
 inline bool Sample(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& k) {
   switch (cx.scene.integrator) {
     case caster::IT_AO: return Ao(cx, pixel, iter, color, k);
@@ -1575,7 +1968,8 @@ int oracle_render_rows(oracle_ctx* c, uint32_t first_iter, uint32_t n_iter, int 
   const uint32_t H = (uint32_t)y1;
   if (threads <= 0) threads = 1;
   std::vector<Counters> ks(threads);
-  if (cx.scene.integrator == caster::IT_LT) {
+  if (cx.scene.integrator == caster::IT_LT || cx.scene.integrator == caster::IT_BDPT) {
+    const bool bdpt = cx.scene.integrator == caster::IT_BDPT;
     // Light paths splat anywhere on the film: rows [y0, y1) select which paths are traced, not
     // where they land.  Each thread takes a fixed share of the rows and splats into a buffer of
     // its own; per iteration the buffers are summed in thread order (kernel_color) and added to
@@ -1590,7 +1984,10 @@ int oracle_render_rows(oracle_ctx* c, uint32_t first_iter, uint32_t n_iter, int 
         uint32_t r0 = (uint32_t)y0 + (uint32_t)((uint64_t)rows * tid / threads);
         uint32_t r1 = (uint32_t)y0 + (uint32_t)((uint64_t)rows * (tid + 1) / threads);
         for (uint32_t y = r0; y < r1; ++y)
-          for (uint32_t x = 0; x < W; ++x) LightTracing(cx, x + y * W, first_iter + it, color[tid].data(), ks[tid]);
+          for (uint32_t x = 0; x < W; ++x) {
+            if (bdpt) Bdpt(cx, x + y * W, first_iter + it, color[tid].data(), ks[tid]);
+            else LightTracing(cx, x + y * W, first_iter + it, color[tid].data(), ks[tid]);
+          }
       };
       std::vector<std::thread> pool;
       for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
@@ -1659,7 +2056,7 @@ int oracle_primary_ids(oracle_ctx* c, uint32_t iter, int32_t* ids) {
       ids[p] = LightStart(cx, p, iter, rng, ray, beta, radiance) && Intersect(cx, ray, &is, k, RK_EXT) ? is.prim : -1;
       continue;
     }
-    Ray ray = CameraSample(cx, p, iter, rng);
+    Ray ray = cx.scene.integrator == caster::IT_BDPT ? BdptCameraRay(cx, p, rng) : CameraSample(cx, p, iter, rng);
     if (cx.scene.integrator == caster::IT_VPT) ray.medium = cx.scene.camera.medium;
     ids[p] = Intersect(cx, ray, &is, k, RK_EXT) ? is.prim : -1;
   }

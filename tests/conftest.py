@@ -30,6 +30,9 @@ SMALL_SCENES = {
     "cornell_lt": dict(name="cornell_lt", width=96, height=96),
     "cornell_fog_lt": dict(name="cornell_fog_lt", width=96, height=96, depth=8),
     "cornell_smoke_lt": dict(name="cornell_smoke_lt", width=96, height=96, depth=8),
+    "cornell_bdpt": dict(name="cornell_bdpt", width=96, height=96),
+    "cornell_fog_bdpt": dict(name="cornell_fog_bdpt", width=96, height=96),
+    "cornell_smoke_bdpt": dict(name="cornell_smoke_bdpt", width=96, height=96),
     "knot_pt": dict(name="knot_pt", width=96, height=96, detail=0.08),
     "stairs_pt": dict(name="stairs_pt", width=128, height=72, detail=0.08),
     "car_pt": dict(name="car_pt", width=128, height=72, detail=0.01),

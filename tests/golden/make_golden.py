@@ -30,10 +30,11 @@ SCENES = {
     "car_env": dict(name="car_pt", width=80, height=48, detail=0.004, env=True),
 }
 SPP = 8
-# Light tracing: a film and a first-hit map only (the per-function vectors above are those of the
+# Light tracing and bidirectional path tracing: a film and a first-hit map only (the per-function vectors above are those of the
 # camera-side integrators).  The film's rounding depends on the oracle's thread count: fixed at 4.
 LT_SCENES = {
     "cornell_fog_lt": dict(name="cornell_fog_lt", width=64, height=64, depth=8),
+    "cornell_fog_bdpt": dict(name="cornell_fog_bdpt", width=48, height=48),
 }
 LT_SPP, LT_THREADS = 4, 4
 

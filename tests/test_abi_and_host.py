@@ -74,7 +74,7 @@ def test_parser_ao_and_lights(caster, tmp_path):
 
 @pytest.mark.parametrize("doc,needle", [
     ({"material": []}, "camera"),                                                    # parsescene.cpp:176-179
-    ({"camera": {}, "integrator": "bdpt"}, "integrator"),                           # out of scope: rejected
+    ({"camera": {}, "integrator": "sppm"}, "integrator"),                           # out of scope: rejected
     ({"camera": {}, "scene": [{"mesh": "q.obj", "material": "nope"}]}, "no material named"),  # :384-385
     ({"camera": {}, "scene": [{"cube": True}]}, "format"),                           # :488-491
     ({"camera": {}, "medium": [{"name": "a", "type": "heterogeneous"}]}, "heterogeneous medium needs"),

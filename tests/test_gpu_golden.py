@@ -42,6 +42,28 @@ def test_against_golden(caster, key):
     r.close()
 
 
+SPLAT = json.load(open(os.path.join(GOLD, "light_tracing.json")))
+
+
+@pytest.mark.parametrize("key", sorted(SPLAT))
+def test_splatting_integrators_against_golden(caster, key):
+    """Light tracing and BDPT: ids and ray counts exact, the film a sum of the same numbers in
+    another order (float atomics): relRMSE <= 1e-5."""
+    sv = SPLAT[key]
+    sc = caster.Scene(os.path.join(GOLD, "scenes", key, "scene.json"))
+    r = caster.Renderer(sc, 0, 3)
+    np.testing.assert_array_equal(r.primary_ids(1), np.load(os.path.join(GOLD, key + "_ids.npy")))
+    r.render(1, sv["spp"], True)
+    film = r.read_film(2)
+    gold = np.load(os.path.join(GOLD, key + "_sum.npy"))
+    assert rel_rmse(film, gold) <= 1e-5
+    st = r.stats()
+    assert st["rays"][3] == sv["counts"]["rays"][3] and st["stack_overflow"] == 0
+    if caster.INTEGRATOR_NAMES[sc.integrator] == "bdpt":
+        assert st["rays"][0] == sv["counts"]["rays"][0]
+    r.close()
+
+
 def test_batching_streams_and_call_splitting_do_not_change_bits(caster):
     """The film is accumulated in iteration order whatever the batch size, the number of
     HIP streams the batches are dealt to, and the way the calls split the iterations."""

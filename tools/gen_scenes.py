@@ -15,6 +15,7 @@ reference's JSON schema (CUDA-PathTracer/tracer/parsescene.cpp:46-598):
   cornell_meshlight  Cornell box lit by 34 emissive triangles
   cornell_smoke  Cornell box with a heterogeneous medium (density grid) in an index-matched box
   cornell_lt / cornell_fog_lt / cornell_smoke_lt  the pt, vpt and smoke boxes under the light-tracing integrator
+  cornell_bdpt / cornell_fog_bdpt / cornell_smoke_bdpt  the same three boxes under bidirectional path tracing
   cornell_vpt  Cornell box with a homogeneous medium inside an index-matched
                box boundary and a glass sphere, volumetric path tracing
   car_pt       "bmw-m6" stand-in: >= 1 M triangle displaced body, glass
@@ -376,6 +377,30 @@ def scene_cornell_smoke_lt(out, a):
     return s
 
 
+def scene_cornell_bdpt(out, a):
+    """The path-traced Cornell box (mirror and glass spheres), rendered by bidirectional path tracing."""
+    s = scene_cornell_pt(out, a)
+    s["integrator"] = "bdpt"
+    return s
+
+
+def scene_cornell_fog_bdpt(out, a):
+    """BDPT through the homogeneous fog of cornell_vpt: medium vertices on both sub-paths,
+    index-matched boundaries, transmittance on every connection."""
+    s = scene_cornell_vpt(out, a)
+    s["integrator"] = "bdpt"
+    s["screen_width"], s["screen_height"] = a.width or 512, a.height or 512
+    return s
+
+
+def scene_cornell_smoke_bdpt(out, a):
+    """BDPT through the density grid of cornell_smoke (connections draw random numbers)."""
+    s = scene_cornell_smoke(out, a)
+    s["integrator"] = "bdpt"
+    s["screen_width"], s["screen_height"] = a.width or 512, a.height or 512
+    return s
+
+
 def scene_knot_pt(out, a):
     d = a.detail
     nu, nv = max(24, int(600 * d)), max(8, int(128 * d))
@@ -524,6 +549,8 @@ SCENES = {
     "cornell_ao": scene_cornell_ao, "cornell_pt": scene_cornell_pt, "cornell_vpt": scene_cornell_vpt,
     "cornell_smoke": scene_cornell_smoke, "cornell_meshlight": scene_cornell_meshlight,
     "cornell_lt": scene_cornell_lt, "cornell_fog_lt": scene_cornell_fog_lt, "cornell_smoke_lt": scene_cornell_smoke_lt,
+    "cornell_bdpt": scene_cornell_bdpt, "cornell_fog_bdpt": scene_cornell_fog_bdpt,
+    "cornell_smoke_bdpt": scene_cornell_smoke_bdpt,
     "knot_pt": scene_knot_pt, "stairs_pt": scene_stairs_pt, "car_pt": scene_car_pt,
 }
 
