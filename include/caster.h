@@ -33,7 +33,7 @@ enum {
 
 typedef struct caster_scene_info {
   int32_t width, height;
-  int32_t integrator;      /* 0 ao, 1 pt, 2 vpt (IntegratorType, scene.h:13-22) */
+  int32_t integrator;      /* 0 ao, 1 pt, 2 vpt, 3 lt, 4 bdpt (IntegratorType, scene.h:13-22) */
   int32_t max_depth;
   int32_t n_prims, n_nodes, n_lights, n_materials, n_media, n_textures;
   int32_t has_environment;
