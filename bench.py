@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--spp-per-step", type=int, default=96)
+    ap.add_argument("--spp-per-step", type=int, default=192)
     ap.add_argument("--iters-in-flight", type=int, default=0, help="iterations per batch of paths (0: library default)")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams batches are dealt to (0: library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (roofline then uses no counts)")

@@ -459,8 +459,8 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   if (default_pool) {
     // late bounces keep few rays alive: a batch needs tens of millions of paths
     // for their launches to fill the chip (the pools are sized for 288 GB of HBM:
-    // 64 M slots x 380 B per stream)
-    long long target = 64ll << 20;
+    // 128 M slots x 380 B per stream)
+    long long target = 128ll << 20;
     iters_in_flight = (int)std::max<long long>(1, std::min<long long>(64, target / S.slots_per_iter));
   }
   if (n_streams <= 0) n_streams = kDefaultStreams;
