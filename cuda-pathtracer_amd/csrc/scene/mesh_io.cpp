@@ -4,6 +4,7 @@
 // formats the synthetic scenes use: Wavefront OBJ and binary PLY meshes,
 // binary PPM / 8-bit PNG textures, PFM environment maps.
 #include <zlib.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -313,15 +314,26 @@ bool load_texture_file(const std::string& path, Texture& out, std::string& err) 
   return true;
 }
 
-// PFM (PF, 3 x float32, bottom row first when the scale is negative = little
-// endian).  Stored top row first, like the row order tinyexr hands to the
-// reference (imageio.cpp:81-103).
-bool load_envmap_file(const std::string& path, Infinite& out, std::string& err) {
-  std::string data;
-  if (!read_file(path, data)) { err = "cannot open environment map \"" + path + "\""; return false; }
-  if (data.size() < 3 || data[0] != 'P' || data[1] != 'F') {
-    err = "environment map \"" + path + "\" must be a PFM (PF) file"; return false;
-  }
+namespace {
+
+float half_to_float(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u, bits;
+  if (e == 0) {
+    if (m == 0) bits = sign;
+    else {  // subnormal half: normalise
+      int shift = 0;
+      while (!(m & 1024u)) { m <<= 1; ++shift; }
+      bits = sign | ((uint32_t)(113 - shift) << 23) | ((m & 1023u) << 13);
+    }
+  } else if (e == 31) bits = sign | 0x7f800000u | (m << 13);
+  else bits = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+// PFM (PF, 3 x float32, bottom row first when the scale is negative = little endian).
+bool load_pfm(const std::string& data, Infinite& out, std::string& err) {
   int w = 0, h = 0; float scale = 0.f; int consumed = 0;
   if (sscanf(data.c_str() + 2, "%d %d %f%n", &w, &h, &scale, &consumed) != 3 || w <= 0 || h <= 0) {
     err = "bad PFM header"; return false;
@@ -333,6 +345,148 @@ bool load_envmap_file(const std::string& path, Infinite& out, std::string& err) 
   out.data.resize((size_t)w * h);
   for (int y = 0; y < h; ++y)
     memcpy(&out.data[(size_t)(h - 1 - y) * w], data.data() + p + (size_t)y * w * 12, (size_t)w * 12);
+  return true;
+}
+
+// Single-part scanline OpenEXR with channels R, G, B (half, float or uint; other channels are
+// skipped) stored uncompressed or with RLE / ZIPS / ZIP compression: what tinyexr's LoadEXR hands to
+// the reference (imageio.cpp:81-103) for such a file, rows in the file's y order.  Tiled and
+// multi-part files and the PIZ / PXR24 / B44 / DWA codecs are refused with a message.
+struct ExrIn {
+  const uint8_t* p; size_t n, at = 0; bool ok = true;
+  bool need(size_t k) { if (at + k > n) ok = false; return ok; }
+  std::string str() { std::string s; while (need(1) && p[at]) s.push_back((char)p[at++]); if (ok) ++at; return s; }
+  int32_t i32() { int32_t v = 0; if (need(4)) { memcpy(&v, p + at, 4); at += 4; } return v; }
+  uint64_t u64() { uint64_t v = 0; if (need(8)) { memcpy(&v, p + at, 8); at += 8; } return v; }
+};
+bool load_exr(const std::string& data, Infinite& out, std::string& err) {
+  ExrIn in{(const uint8_t*)data.data(), data.size()};
+  in.i32();
+  int32_t version = in.i32();
+  if ((version & 0xff) != 2 || (version & 0x200) || (version & 0x1000) || (version & 0x800)) {
+    err = "only single-part scanline OpenEXR 2 files are read"; return false;
+  }
+  struct Chan { std::string name; int type; };
+  std::vector<Chan> chans;
+  int compression = -1, x0 = 0, y0 = 0, x1 = -1, y1 = -1;
+  for (;;) {
+    std::string name = in.str();
+    if (!in.ok) { err = "truncated EXR header"; return false; }
+    if (name.empty()) break;
+    std::string type = in.str();
+    int32_t size = in.i32();
+    if (!in.ok || size < 0 || !in.need((size_t)size)) { err = "truncated EXR header"; return false; }
+    size_t end = in.at + (size_t)size;
+    if (name == "channels") {
+      while (in.at < end && in.p[in.at]) {
+        Chan c;
+        c.name = in.str();
+        c.type = in.i32();
+        in.at += 4;  // pLinear, reserved
+        int32_t xs = in.i32(), ys = in.i32();
+        if (xs != 1 || ys != 1) { err = "subsampled EXR channels are not supported"; return false; }
+        if (c.type < 0 || c.type > 2) { err = "bad EXR channel type"; return false; }
+        chans.push_back(c);
+      }
+    } else if (name == "compression") {
+      compression = in.p[in.at];
+    } else if (name == "dataWindow") {
+      x0 = in.i32(); y0 = in.i32(); x1 = in.i32(); y1 = in.i32();
+    }
+    in.at = end;
+  }
+  const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+  if (w <= 0 || h <= 0 || chans.empty()) { err = "EXR header lacks channels or a data window"; return false; }
+  if (compression < 0 || compression > 3) {
+    static const char* names[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
+    err = std::string("EXR compression ") + (compression >= 0 && compression < 10 ? names[compression] : "?") +
+          " is not supported (NONE, RLE, ZIPS and ZIP are)";
+    return false;
+  }
+  int chan_of[3] = {-1, -1, -1};
+  size_t line_bytes = 0;
+  std::vector<size_t> chan_off(chans.size());
+  for (size_t c = 0; c < chans.size(); ++c) {
+    chan_off[c] = line_bytes;
+    line_bytes += (size_t)w * (chans[c].type == 1 ? 2 : 4);
+    if (chans[c].name == "R") chan_of[0] = (int)c;
+    if (chans[c].name == "G") chan_of[1] = (int)c;
+    if (chans[c].name == "B") chan_of[2] = (int)c;
+  }
+  if (chan_of[0] < 0 && chans.size() == 1) chan_of[0] = chan_of[1] = chan_of[2] = 0;  // luminance only
+  if (chan_of[0] < 0 || chan_of[1] < 0 || chan_of[2] < 0) { err = "EXR file has no R, G, B channels"; return false; }
+  const int lines_per_chunk = compression == 3 ? 16 : 1;
+  const int n_chunks = (h + lines_per_chunk - 1) / lines_per_chunk;
+  std::vector<uint64_t> offsets((size_t)n_chunks);
+  for (auto& o : offsets) o = in.u64();
+  if (!in.ok) { err = "truncated EXR offset table"; return false; }
+  out.w = w; out.h = h;
+  out.data.assign((size_t)w * h, f3{0.f, 0.f, 0.f});
+  std::vector<uint8_t> raw, tmp;
+  for (int k = 0; k < n_chunks; ++k) {
+    ExrIn ch{in.p, in.n, (size_t)offsets[k]};
+    int32_t y = ch.i32(), size = ch.i32();
+    if (!ch.ok || size < 0 || !ch.need((size_t)size) || y < y0 || y > y1) { err = "bad EXR chunk"; return false; }
+    const int lines = std::min(lines_per_chunk, y1 - y + 1);
+    const size_t want = line_bytes * (size_t)lines;
+    const uint8_t* src = ch.p + ch.at;
+    if (compression != 0 && (size_t)size < want) {
+      tmp.assign(want, 0);
+      if (compression == 1) {  // run-length: n >= 0 repeats the next byte n + 1 times, n < 0 copies -n bytes
+        size_t i = 0, o = 0;
+        while (i < (size_t)size && o < want) {
+          int n = (int8_t)src[i++];
+          if (n < 0) { size_t c = (size_t)(-n); if (i + c > (size_t)size || o + c > want) break; memcpy(&tmp[o], src + i, c); i += c; o += c; }
+          else { size_t c = (size_t)n + 1; if (i >= (size_t)size || o + c > want) break; memset(&tmp[o], src[i++], c); o += c; }
+        }
+        if (o != want) { err = "bad run-length data in EXR chunk"; return false; }
+      } else {
+        uLongf got = (uLongf)want;
+        if (uncompress(tmp.data(), &got, src, (uLong)size) != Z_OK || got != want) { err = "bad zlib data in EXR chunk"; return false; }
+      }
+      for (size_t i = 1; i < want; ++i) tmp[i] = (uint8_t)(tmp[i - 1] + tmp[i] - 128);  // undo the byte predictor
+      raw.resize(want);
+      const size_t half = (want + 1) / 2;                                                 // and the even/odd split
+      for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];
+      src = raw.data();
+    } else if ((size_t)size != want) {
+      err = "bad EXR chunk size"; return false;
+    }
+    for (int l = 0; l < lines; ++l) {
+      const uint8_t* line = src + (size_t)l * line_bytes;
+      f3* dst = &out.data[(size_t)(y - y0 + l) * w];
+      for (int c = 0; c < 3; ++c) {
+        const Chan& cc = chans[(size_t)chan_of[c]];
+        const uint8_t* q = line + chan_off[(size_t)chan_of[c]];
+        for (int x = 0; x < w; ++x) {
+          float v;
+          if (cc.type == 1) { uint16_t hv; memcpy(&hv, q + 2 * x, 2); v = half_to_float(hv); }
+          else if (cc.type == 2) memcpy(&v, q + 4 * x, 4);
+          else { uint32_t u; memcpy(&u, q + 4 * x, 4); v = (float)u; }
+          (c == 0 ? dst[x].x : c == 1 ? dst[x].y : dst[x].z) = v;
+        }
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+// Environment map: OpenEXR as the reference reads it (parsescene.cpp:551-588, imageio.cpp:81-103),
+// or PFM.  Stored top row first, the row order tinyexr hands to the reference.
+bool load_envmap_file(const std::string& path, Infinite& out, std::string& err) {
+  std::string data;
+  if (!read_file(path, data)) { err = "cannot open environment map \"" + path + "\""; return false; }
+  std::string why;
+  bool ok = false;
+  if (data.size() >= 8 && (uint8_t)data[0] == 0x76 && (uint8_t)data[1] == 0x2f && (uint8_t)data[2] == 0x31 && (uint8_t)data[3] == 0x01)
+    ok = load_exr(data, out, why);
+  else if (data.size() >= 3 && data[0] == 'P' && data[1] == 'F')
+    ok = load_pfm(data, out, why);
+  else
+    why = "must be an OpenEXR or a PFM (PF) file";
+  if (!ok) { err = "environment map \"" + path + "\": " + why; return false; }
   out.valid = 1;
   return true;
 }

@@ -40,7 +40,10 @@ def test_scene_info_of_golden_scenes(caster):
 
 def write_scene(tmp_path, doc, files=()):
     for name, text in files:
-        (tmp_path / name).write_text(text)
+        if isinstance(text, bytes):
+            (tmp_path / name).write_bytes(text)
+        else:
+            (tmp_path / name).write_text(text)
     p = tmp_path / "scene.json"
     p.write_text(json.dumps(doc))
     return str(p)
@@ -194,3 +197,105 @@ def test_image_writers(caster, tmp_path):
         np.testing.assert_array_equal(exr.view(np.uint16), img[::-1].astype(np.float16).view(np.uint16))
     with pytest.raises(caster.CasterError):
         caster.write_image(tmp_path / "a.bmp", img)
+
+
+def _exr_bytes(rows_top_first, pixel_type, compression):
+    """A scanline OpenEXR file written by hand: channels B, G, R of `pixel_type` (1 half, 2 float),
+    `compression` 0 none, 1 run-length, 2 zlib per scanline, 3 zlib per 16 scanlines."""
+    import struct
+    import zlib
+    h, w, _ = rows_top_first.shape
+    dt = np.float16 if pixel_type == 1 else np.float32
+
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(payload)) + payload
+
+    chl = b"".join(n + b"\0" + struct.pack("<iB3xii", pixel_type, 0, 1, 1) for n in (b"B", b"G", b"R")) + b"\0"
+    head = struct.pack("<ii", 20000630, 2)
+    head += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    head += attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box)
+    head += attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1))
+    head += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1))
+    head += b"\0"
+
+    def rle(b):
+        out, i = bytearray(), 0
+        while i < len(b):
+            j = i
+            while j + 1 < len(b) and b[j + 1] == b[i] and j - i < 127:
+                j += 1
+            if j - i >= 2:
+                out += bytes([j - i, b[i]]); i = j + 1
+            else:
+                j = i
+                while j < len(b) and j - i < 127 and not (j + 2 < len(b) and b[j] == b[j + 1] == b[j + 2]):
+                    j += 1
+                out += bytes([(256 - (j - i)) & 255]) + b[i:j]; i = j
+        return bytes(out)
+
+    per = 16 if compression == 3 else 1
+    chunks = []
+    for y in range(0, h, per):
+        raw = b"".join(rows_top_first[l, :, c].astype(dt).tobytes() for l in range(y, min(y + per, h)) for c in (2, 1, 0))
+        data = raw
+        if compression:
+            a = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)
+            t[1:] = (t[1:] - t[:-1] + 128 + 256) & 255
+            packed = rle(bytes(t.astype(np.uint8))) if compression == 1 else zlib.compress(bytes(t.astype(np.uint8)))
+            if len(packed) < len(raw):
+                data = packed
+        chunks.append(struct.pack("<ii", y, len(data)) + data)
+    table_at = len(head)
+    off = table_at + 8 * len(chunks)
+    table = b""
+    for c in chunks:
+        table += struct.pack("<Q", off)
+        off += len(c)
+    return head + table + b"".join(chunks)
+
+
+@pytest.mark.parametrize("pixel_type,compression", [(2, 0), (2, 3), (2, 2), (1, 3), (1, 1), (1, 0)])
+def test_exr_environment_map_equals_pfm(tmp_path, pixel_type, compression):
+    """The reference reads its environment light from OpenEXR (parsescene.cpp:551-588): the same map
+    as .exr (half or float; uncompressed, RLE, ZIPS, ZIP) and as .pfm renders the same image."""
+    import gen_scenes
+    import oracle_lib as ol
+    path = gen_scenes.generate(str(tmp_path / "s"), "car_pt", width=40, height=24, detail=0.004, env=True)
+    d = os.path.dirname(path)
+    doc = json.load(open(path))
+    env = [l for l in doc["light"] if "infinite" in l][0]
+    raw = open(os.path.join(d, env["infinite"]), "rb").read()
+    hdr = raw.split(b"\n", 3)
+    w, h = map(int, hdr[1].split())
+    px = np.frombuffer(hdr[3], "<f4").reshape(h, w, 3)              # PFM: bottom row first
+    px = px.copy()
+    px[:, : w // 3] = px[:, :1]                                      # some constant runs for the run-length coder
+    if pixel_type == 1:
+        px = px.astype(np.float16).astype(np.float32)               # what a half file can hold
+    with open(os.path.join(d, "sky2.pfm"), "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h) + px.astype("<f4").tobytes())
+    with open(os.path.join(d, "sky2.exr"), "wb") as f:
+        f.write(_exr_bytes(px[::-1], pixel_type, compression))       # EXR: top row first
+    films = []
+    for name in ("sky2.pfm", "sky2.exr"):
+        env["infinite"] = name
+        p2 = os.path.join(d, "scene_%s.json" % name[-3:])
+        json.dump(doc, open(p2, "w"))
+        films.append(ol.Oracle(p2).render(1, 2, 4))
+    assert films[0].mean() > 0
+    np.testing.assert_array_equal(films[0], films[1])
+
+
+def test_exr_refusals(caster, tmp_path):
+    import struct
+    px = np.ones((4, 4, 3), np.float32)
+    data = bytearray(_exr_bytes(px, 2, 0))
+    at = data.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    data[at] = 4                                                     # PIZ
+    doc = {"camera": {}, "light": [{"infinite": "e.exr"}]}
+    with pytest.raises(caster.CasterError, match="PIZ"):
+        caster.Scene(write_scene(tmp_path, doc, [("e.exr", bytes(data))]))
+    with pytest.raises(caster.CasterError, match="OpenEXR or a PFM"):
+        caster.Scene(write_scene(tmp_path, doc, [("e.exr", b"not an image")]))
