@@ -9,6 +9,8 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <unordered_map>
+#include <cmath>
 #include "scene.h"
 
 namespace caster {
@@ -34,6 +36,8 @@ bool read_file(const std::string& path, std::string& out) {
 
 // OBJ: one output vertex per face corner (assimp's OBJ importer does not
 // share vertices unless asked to join them), polygons fan-triangulated.
+// A file without any normals gets smooth ones (below).
+void smooth_normals(RawMesh& m);
 bool load_obj(const std::string& path, RawMesh& m, std::string& err) {
   std::string text;
   if (!read_file(path, text)) { err = "cannot open mesh \"" + path + "\""; return false; }
@@ -43,6 +47,7 @@ bool load_obj(const std::string& path, RawMesh& m, std::string& err) {
   const char* s = text.c_str();
   const char* end = s + text.size();
   std::vector<int> corner;  // v, vt, vn triples of the current face
+  size_t with_normal = 0, without_normal = 0;
   while (s < end) {
     const char* le = (const char*)memchr(s, '\n', (size_t)(end - s));
     if (!le) le = end;
@@ -89,13 +94,11 @@ bool load_obj(const std::string& path, RawMesh& m, std::string& err) {
         for (int c = 0; c < 3; ++c) {
           int v = corner[3 * tri[c]], vt = corner[3 * tri[c] + 1], vn = corner[3 * tri[c] + 2];
           if (v < 1 || v > (int)P.size()) { err = "bad vertex index in \"" + path + "\""; return false; }
-          if (vn < 1 || vn > (int)N.size()) {
-            err = "mesh \"" + path + "\" has a face without a normal (vn is required)";
-            return false;
-          }
+          const bool has_n = vn >= 1 && vn <= (int)N.size();
+          ++(has_n ? with_normal : without_normal);
           m.idx.push_back((int)m.pos.size());
           m.pos.push_back(P[v - 1]);
-          m.nrm.push_back(N[vn - 1]);
+          m.nrm.push_back(has_n ? N[vn - 1] : f3{0.f, 0.f, 0.f});
           if (vt >= 1 && vt <= (int)T.size()) { m.uv.push_back(T[vt - 1]); any_uv = true; }
           else m.uv.push_back(f2{0.f, 0.f});
         }
@@ -105,7 +108,55 @@ bool load_obj(const std::string& path, RawMesh& m, std::string& err) {
   }
   if (!any_uv) m.uv.clear();
   if (m.idx.empty()) { err = "mesh \"" + path + "\" has no faces"; return false; }
+  if (without_normal && with_normal) {
+    err = "mesh \"" + path + "\" has faces with and faces without normals";
+    return false;
+  }
+  if (without_normal) smooth_normals(m);
   return true;
+}
+
+// Normals for a mesh that has none, after assimp's aiProcess_GenSmoothNormals, which the reference
+// asks for (parsescene.cpp:390,537): every corner takes its triangle's unit normal, and all corners
+// at one position share the normalised sum of theirs (no angle limit, assimp's default).  The
+// reference's assimp version is not pinned and only ships as a Windows binary, so this is written
+// from the algorithm's description, not checked against it; corners are matched by exact position
+// where assimp matches within 1e-5 of the mesh's extent.
+void smooth_normals(RawMesh& m) {
+  struct Key {
+    uint32_t x, y, z;
+    bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; }
+  };
+  struct Hash {
+    size_t operator()(const Key& k) const { return (size_t)k.x * 73856093u ^ (size_t)k.y * 19349663u ^ (size_t)k.z * 83492791u; }
+  };
+  auto key = [](f3 p) {
+    Key k;
+    float c[3] = {p.x + 0.f, p.y + 0.f, p.z + 0.f};  // -0 -> +0
+    memcpy(&k, c, 12);
+    return k;
+  };
+  std::unordered_map<Key, f3, Hash> sum;
+  std::vector<f3> face(m.idx.size() / 3);
+  for (size_t t = 0; t < face.size(); ++t) {
+    f3 a = m.pos[(size_t)m.idx[3 * t]], b = m.pos[(size_t)m.idx[3 * t + 1]], c = m.pos[(size_t)m.idx[3 * t + 2]];
+    f3 e1 = {b.x - a.x, b.y - a.y, b.z - a.z}, e2 = {c.x - a.x, c.y - a.y, c.z - a.z};
+    f3 n = {e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x};
+    float len = sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+    if (len > 0.f) n = f3{n.x / len, n.y / len, n.z / len};
+    face[t] = n;
+    for (int k = 0; k < 3; ++k) {
+      f3& s = sum[key(m.pos[(size_t)m.idx[3 * t + k]])];
+      s = f3{s.x + n.x, s.y + n.y, s.z + n.z};
+    }
+  }
+  for (size_t t = 0; t < face.size(); ++t)
+    for (int k = 0; k < 3; ++k) {
+      size_t v = (size_t)m.idx[3 * t + k];
+      f3 s = sum[key(m.pos[v])];
+      float len = sqrtf(s.x * s.x + s.y * s.y + s.z * s.z);
+      m.nrm[v] = len > 0.f ? f3{s.x / len, s.y / len, s.z / len} : face[t];
+    }
 }
 
 // Binary little-endian PLY with float x,y,z,nx,ny,nz[,s,t|u,v] vertices and

@@ -299,3 +299,37 @@ def test_exr_refusals(caster, tmp_path):
         caster.Scene(write_scene(tmp_path, doc, [("e.exr", bytes(data))]))
     with pytest.raises(caster.CasterError, match="OpenEXR or a PFM"):
         caster.Scene(write_scene(tmp_path, doc, [("e.exr", b"not an image")]))
+
+
+def test_obj_without_normals_gets_smooth_ones(caster, tmp_path):
+    """parsescene.cpp:390 asks assimp for aiProcess_GenSmoothNormals: an OBJ without vn renders
+    like the same mesh with the averaged unit face normals written out."""
+    import oracle_lib as ol
+    v = [(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)]
+    quads = [(1, 2, 4, 3), (5, 7, 8, 6), (1, 5, 6, 2), (3, 4, 8, 7), (1, 3, 7, 5), (2, 6, 8, 4)]   # outward
+    bare = "".join("v %g %g %g\n" % p for p in v) + "".join("f %d %d %d %d\n" % q for q in quads)
+    # fan triangulation: the quad's first and third corner lie in two triangles
+    acc = {i: np.zeros(3) for i in range(1, 9)}
+    for q in quads:
+        p = [np.array(v[i - 1], float) for i in q]
+        n = np.cross(p[1] - p[0], p[2] - p[0]); n /= np.linalg.norm(n)
+        for i, times in zip(q, (2, 1, 2, 1)):
+            acc[i] += times * n
+    with_n = "".join("v %g %g %g\n" % p for p in v)
+    with_n += "".join("vn %.9g %.9g %.9g\n" % tuple(np.float32(acc[i] / np.linalg.norm(acc[i]))) for i in range(1, 9))
+    with_n += "".join("f " + " ".join("%d//%d" % (i, i) for i in q) + "\n" for q in quads)
+    light = "v -1 3 -1\nv 2 3 -1\nv 2 3 2\nv -1 3 2\nvn 0 -1 0\nf 1//1 2//1 3//1 4//1\n"
+    films = []
+    for name, text in (("bare", bare), ("withn", with_n)):
+        d = tmp_path / name
+        d.mkdir()
+        doc = {"screen_width": 32, "screen_height": 32, "camera": {"position": [3, 2.5, 4], "lookat": [0.5, 0.5, 0.5], "fov": 30},
+               "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [0.7, 0.6, 0.5]}],
+               "scene": [{"mesh": "c.obj", "material": "m"}], "light": [{"mesh": "l.obj", "material": "m", "radiance": [9, 9, 9]}]}
+        films.append(ol.Oracle(write_scene(d, doc, [("c.obj", text), ("l.obj", light)])).render(1, 4, 2))
+    assert films[0].mean() > 0.01
+    assert np.abs(films[0] - films[1]).max() <= 1e-4 * films[0].max()   # normals differ in the last bit at most
+    mixed = "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1 2 3\n"
+    with pytest.raises(caster.CasterError, match="with and faces without normals"):
+        caster.Scene(write_scene(tmp_path, {"camera": {}, "material": [{"name": "m", "bsdf": "mirror"}],
+                                            "scene": [{"mesh": "x.obj", "material": "m"}]}, [("x.obj", mixed)]))
