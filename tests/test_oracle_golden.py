@@ -145,3 +145,52 @@ def test_tonemap_matches_formula():
     g = o.tonemap(x, False)
     ref = np.power(np.maximum(x.astype(np.float64), 1e-5) * 1.41421356, 1 / 2.2)
     np.testing.assert_allclose(g, ref, rtol=1e-5)
+
+
+def test_sample_camera_inverts_primary_rays():
+    """Camera::SampleCamera (Camera.h:87-118) against GeneratePrimaryRay (:45-85): a point on the
+    primary ray of pixel (x, y) is seen by the pinhole at that pixel (the raster position is rounded
+    to a grid of res - 1 steps, so the neighbour is allowed), with density dist^2 / cos and
+    importance d^2 / (A cos^4), A = 4 * half width * half height of the image plane at distance
+    d = 0.1 (parsescene.cpp:608); a point behind the camera is not seen."""
+    path = scene_path("cornell_fog_lt")
+    o = ol.Oracle(path)
+    W, H = o.width, o.height
+    fov = json.load(open(path))["camera"].get("fov", 60.0)
+    d = 0.1
+    half_h = np.tan(np.radians(fov * 0.5)) * d
+    area = 4.0 * (half_h * W / H) * half_h
+    rng = np.random.RandomState(3)
+    for _ in range(200):
+        x, y = int(rng.randint(1, W - 1)), int(rng.randint(1, H - 1))
+        ray = o.camera_ray(x, y, 1 + int(rng.randint(50))).astype(np.float64)
+        org, dr = ray[:3], ray[3:]
+        t = rng.uniform(0.5, 6.0)
+        raster, (we, pdf, tmax) = o.sample_camera(org + t * dr)
+        assert raster >= 0
+        rx, ry = raster % W, raster // W
+        assert abs(rx - x) <= 1 and abs(ry - y) <= 1
+        assert abs(tmax - (t - 1e-3)) < 1e-3
+        cos = t * t / pdf                      # pdf = dist^2 / cos
+        assert 0 < cos <= 1 + 1e-5
+        assert abs(we * area * cos ** 4 / (d * d) - 1) < 1e-3
+    centre = o.camera_ray(W // 2, H // 2, 1).astype(np.float64)
+    raster, (we, pdf, tmax) = o.sample_camera(centre[:3] - 2.0 * centre[3:])
+    assert raster == -1 and pdf == 0
+
+
+def test_bidirectional_and_unidirectional_estimators_agree(tmp_path):
+    """Path tracing and BDPT estimate the same image (BDPT without the depth limit, so slightly
+    brighter): block means of the Cornell box agree within noise.  Guards the MIS weights, which
+    no bit-exact comparison between two implementations of the same formulas can."""
+    import gen_scenes
+    films = {}
+    for name in ("cornell_pt", "cornell_bdpt"):
+        path = gen_scenes.generate(str(tmp_path / name), name, width=32, height=32, depth=12)
+        films[name] = ol.Oracle(path).render(1, 192, 8) / 192.0
+    pt = films["cornell_pt"].reshape(4, 8, 4, 8, 3).mean(axis=(1, 3))
+    bd = films["cornell_bdpt"].reshape(4, 8, 4, 8, 3).mean(axis=(1, 3))
+    ratio = bd.sum() / pt.sum()
+    assert 0.97 < ratio < 1.08, ratio
+    rel = np.abs(bd - pt).sum(axis=2) / (pt.sum(axis=2) + 1e-3)
+    assert np.median(rel) < 0.1, rel
