@@ -2754,7 +2754,7 @@ __global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter
   __shared__ uint2 s_stack[kLdsDepth][kWave];
   __shared__ uint32_t s_end[kWave + 1];  // joins of the samples of lanes < i
   __shared__ uint32_t s_rng[kWave];
-  __shared__ int s_nl[kWave];
+  __shared__ int s_nl[kWave], s_nc[kWave];
   __shared__ float s_own[kWave][3];      // what the joins with s >= 2 add to each sample's own pixel
   Stack st{s_stack, aux.spill + (blockIdx.x * kWave + threadIdx.x), aux.spill_stride, 0};
   const DevScene& S = L.S;
@@ -2832,44 +2832,56 @@ __global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter
       if (!is_black(own)) splat(S, acc, (int)pixel, own);
       continue;
     }
-    // the wavefront's joins, numbered sample by sample in (s, t) order, dealt to the lanes round-robin
+    // The wavefront's joins are dealt to its lanes round-robin, one kind of join at a time (emitter
+    // hits, sampled light points, pinhole, inner vertices: the four branches of Connect()), so that
+    // the lanes of a step run the same branch.
     __syncthreads();  // the previous round's readers of the tables below are done
     s_rng[lane] = rng;
     s_nl[lane] = nLight;
+    s_nc[lane] = nCamera;
     s_own[lane][0] = 0.f; s_own[lane][1] = 0.f; s_own[lane][2] = 0.f;
-    {
-      uint32_t mine = (uint32_t)(nCamera * (nLight + 1)), incl = mine;
-      for (int off = 1; off < kWave; off <<= 1) {
-        uint32_t up = (uint32_t)__shfl_up((int)incl, off, kWave);
-        if ((int)lane >= off) incl += up;
+    for (int kind = 0; kind < 4; ++kind) {
+      {
+        const int cs = nCamera - 1 > 0 ? nCamera - 1 : 0, lt = nLight - 1 > 0 ? nLight - 1 : 0;
+        uint32_t mine = (uint32_t)(kind == 0 ? cs : kind == 1 ? (nLight >= 1 ? cs : 0) : kind == 2 ? (nCamera >= 1 ? lt : 0) : cs * lt);
+        uint32_t incl = mine;
+        for (int off = 1; off < kWave; off <<= 1) {
+          uint32_t up = (uint32_t)__shfl_up((int)incl, off, kWave);
+          if ((int)lane >= off) incl += up;
+        }
+        __syncthreads();  // the previous kind's readers of s_end are done
+        s_end[lane + 1] = incl;
+        if (lane == 0) s_end[0] = 0;
+        __syncthreads();
       }
-      s_end[lane + 1] = incl;
-      if (lane == 0) s_end[0] = 0;
-    }
-    __syncthreads();
-    const uint32_t wave_joins = s_end[kWave];
-    for (uint32_t j = lane; j < wave_joins; j += kWave) {
-      uint32_t lo = 0, hi = kWave - 1;  // the sample i with s_end[i] <= j < s_end[i + 1]
-      while (lo < hi) {
-        uint32_t mid = (lo + hi + 1) >> 1;
-        if (s_end[mid] <= j) lo = mid;
-        else hi = mid - 1;
-      }
-      const uint32_t i = lo;
-      const int nl = s_nl[i];
-      const uint32_t in_sample = j - s_end[i];
-      const int s = 1 + (int)(in_sample / (uint32_t)(nl + 1)), t = (int)(in_sample % (uint32_t)(nl + 1));
-      if (s == 1 && t <= 1) continue;
-      // draws of the joins before this one: three for every (s', 1) with 2 <= s' < s, three more past (s, 1)
-      uint32_t draws = nl >= 1 ? 3u * (uint32_t)(s - 2 > 0 ? s - 2 : 0) + (s >= 2 && t > 1 ? 3u : 0u) : 0u;
-      uint32_t jr = rng_skip(s_rng[i], draws);
-      int raster = -1;
-      V3 Lc = bdpt_connect(S, st, L.stats, V, g0 + i, s, t, raster, jr, n_tr);
-      if (has_inf(Lc) || has_nan(Lc) || is_black(Lc)) continue;
-      if (s == 1) {
-        splat(S, acc, raster, Lc);
-      } else {  // gathered in LDS: one add to the film per sample instead of one per join
-        atomicAdd(&s_own[i][0], Lc.x); atomicAdd(&s_own[i][1], Lc.y); atomicAdd(&s_own[i][2], Lc.z);
+      const uint32_t wave_joins = s_end[kWave];
+      for (uint32_t j = lane; j < wave_joins; j += kWave) {
+        uint32_t lo = 0, hi = kWave - 1;  // the sample i with s_end[i] <= j < s_end[i + 1]
+        while (lo < hi) {
+          uint32_t mid = (lo + hi + 1) >> 1;
+          if (s_end[mid] <= j) lo = mid;
+          else hi = mid - 1;
+        }
+        const uint32_t i = lo;
+        const int nl = s_nl[i];
+        const uint32_t in_sample = j - s_end[i];
+        int s, t;
+        if (kind == 0) { s = 2 + (int)in_sample; t = 0; }
+        else if (kind == 1) { s = 2 + (int)in_sample; t = 1; }
+        else if (kind == 2) { s = 1; t = 2 + (int)in_sample; }
+        else { s = 2 + (int)(in_sample / (uint32_t)(nl - 1)); t = 2 + (int)(in_sample % (uint32_t)(nl - 1)); }
+        // draws of the joins before this one in the reference's order: three for every (s', 1) with
+        // 2 <= s' < s, three more past (s, 1)
+        uint32_t draws = nl >= 1 ? 3u * (uint32_t)(s - 2 > 0 ? s - 2 : 0) + (s >= 2 && t > 1 ? 3u : 0u) : 0u;
+        uint32_t jr = rng_skip(s_rng[i], draws);
+        int raster = -1;
+        V3 Lc = bdpt_connect(S, st, L.stats, V, g0 + i, s, t, raster, jr, n_tr);
+        if (has_inf(Lc) || has_nan(Lc) || is_black(Lc)) continue;
+        if (s == 1) {
+          splat(S, acc, raster, Lc);
+        } else {  // gathered in LDS: one add to the film per sample instead of one per join
+          atomicAdd(&s_own[i][0], Lc.x); atomicAdd(&s_own[i][1], Lc.y); atomicAdd(&s_own[i][2], Lc.z);
+        }
       }
     }
     __syncthreads();
