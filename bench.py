@@ -216,17 +216,19 @@ def main():
             o = ol.Oracle(path)
             threads = a.cpu_threads or min(os.cpu_count() or 1, 16)
             c = ol.Counts()
-            # bounded sample: every 8th block of 8 scanlines of the frame, 1 spp
-            sample_rows = [(y, min(y + 8, scene.height)) for y in range(0, scene.height, 64)]
+            # bounded sample (some 15 s of CPU work): 32 scanlines out of every 128 of the frame, 4 spp;
+            # the oracle hands out whole scanlines, so a block of 32 keeps 16 threads busy
+            cpu_spp = 4
+            sample_rows = [(y, min(y + 32, scene.height)) for y in range(0, scene.height, 128)]
             t0 = time.perf_counter()
             for y0, y1 in sample_rows:
-                o.render(1, 1, threads, counts=c, rows=(y0, y1))
+                o.render(1, cpu_spp, threads, counts=c, rows=(y0, y1))
             tc = time.perf_counter() - t0
             n_cpu = c.samples
             c1 = ol.Counts()
             y_mid = scene.height // 2
             t0 = time.perf_counter()
-            o.render(1, 1, 1, counts=c1, rows=(y_mid, min(y_mid + 4, scene.height)))
+            o.render(1, 1, 1, counts=c1, rows=(y_mid, min(y_mid + 16, scene.height)))
             tc1 = time.perf_counter() - t0
             counts = c.as_dict()
             cpu_model = ""
@@ -237,8 +239,8 @@ def main():
                 pass
             out["cpu_baseline"] = {
                 "value": n_cpu / tc / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
-                "sample": "%d samples: 1 spp on every 8th block of 8 scanlines of the same %dx%d frame" % (
-                    n_cpu, scene.width, scene.height),
+                "sample": "%d samples: %d spp on 32 scanlines out of every 128 of the same %dx%d frame" % (
+                    n_cpu, cpu_spp, scene.width, scene.height),
                 "single_thread_msamples_per_s": c1.samples / tc1 / 1e6,
                 "mrays_per_s": sum(counts["rays"]) / tc / 1e6,
             }
