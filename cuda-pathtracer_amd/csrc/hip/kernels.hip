@@ -617,6 +617,8 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
   // this wavefront's first chunk is assigned statically (no atomic storm at
   // launch): the work counters start at the end of the static assignment
   const uint32_t part = ((count + kWorkShards - 1) / kWorkShards + kWave - 1) / kWave * kWave;
+  // where the work counters start: past the statically assigned first chunk of every wavefront
+  const uint32_t work_init = (gridDim.x * kTraceBlockWaves + kWorkShards - 1) / kWorkShards * kChunk;
   uint32_t shard = wave_id % kWorkShards, shards_tried = 0;
   uint32_t chunk_next, chunk_end;
   {
@@ -652,14 +654,19 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
         // counter would bound the kernel.  A wavefront works on "its" part
         // first and moves on to the next part when that one is exhausted.
         while (shards_tried < kWorkShards) {
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(aux.work + shard * kWorkPad, kChunk);
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
           uint32_t lo = shard * part, hi = lo + part < count ? lo + part : count;
-          if (lo + base < hi) {
-            chunk_next = lo + base;
-            chunk_end = chunk_next + kChunk < hi ? chunk_next + kChunk : hi;
-            break;
+          // A part whose rays were all handed out statically needs no atomic to be found empty: in a
+          // launch over a short queue that is every part, and 5120 wavefronts asking eight counters
+          // in turn would take longer than the tracing (same-address atomics retire at ~20 per us).
+          if (lo + work_init < hi) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(aux.work + shard * kWorkPad, kChunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (lo + base < hi) {
+              chunk_next = lo + base;
+              chunk_end = chunk_next + kChunk < hi ? chunk_next + kChunk : hi;
+              break;
+            }
           }
           shard = shard + 1 == kWorkShards ? 0 : shard + 1;
           ++shards_tried;
