@@ -617,15 +617,20 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
   // this wavefront's first chunk is assigned statically (no atomic storm at
   // launch): the work counters start at the end of the static assignment
   const uint32_t part = ((count + kWorkShards - 1) / kWorkShards + kWave - 1) / kWave * kWave;
-  // where the work counters start: past the statically assigned first chunk of every wavefront
-  const uint32_t work_init = (gridDim.x * kTraceBlockWaves + kWorkShards - 1) / kWorkShards * kChunk;
+  // Rays are claimed kChunk at a time from a short queue (so that they spread over all wavefronts)
+  // and up to four times as many at a time from a long one (fewer trips to the work counters).
+  const uint32_t n_waves = gridDim.x * kTraceBlockWaves;
+  const uint32_t per_wave = count / (n_waves * kChunk);
+  const uint32_t chunk = per_wave >= 16 ? 4 * kChunk : per_wave >= 8 ? 2 * kChunk : kChunk;
+  // the work counters count from the end of the statically assigned first chunk of every wavefront
+  const uint32_t work_init = (n_waves + kWorkShards - 1) / kWorkShards * chunk;
   uint32_t shard = wave_id % kWorkShards, shards_tried = 0;
   uint32_t chunk_next, chunk_end;
   {
     uint32_t lo = shard * part, hi = lo + part < count ? lo + part : count;
-    uint32_t base = (wave_id / kWorkShards) * kChunk;
+    uint32_t base = (wave_id / kWorkShards) * chunk;
     chunk_next = lo + base < hi ? lo + base : 0;
-    chunk_end = lo + base < hi ? (chunk_next + kChunk < hi ? chunk_next + kChunk : hi) : 0;
+    chunk_end = lo + base < hi ? (chunk_next + chunk < hi ? chunk_next + chunk : hi) : 0;
   }
   bool more = true;
   for (;;) {
@@ -660,11 +665,11 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
           // in turn would take longer than the tracing (same-address atomics retire at ~20 per us).
           if (lo + work_init < hi) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(aux.work + shard * kWorkPad, kChunk);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (lane == 0) base = atomicAdd(aux.work + shard * kWorkPad, chunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + work_init;
             if (lo + base < hi) {
               chunk_next = lo + base;
-              chunk_end = chunk_next + kChunk < hi ? chunk_next + kChunk : hi;
+              chunk_end = chunk_next + chunk < hi ? chunk_next + chunk : hi;
               break;
             }
           }
@@ -3397,7 +3402,7 @@ __global__ void k_gather_ids(LaunchCtx L, RayQueue q, int32_t* ids) {
 __global__ void k_roll(Stats* st, const uint32_t* n_ext, const uint32_t* n_shadow, const uint32_t* n_probe,
                        uint32_t* clear0, uint32_t* clear1, uint32_t* clear2, uint32_t ext_override, uint32_t* work,
                        uint32_t n_work, uint32_t work_init) {
-  // work counters start past the statically assigned first chunk of every wavefront
+  // work counters start at zero (k_trace adds the size of its static assignment itself)
   for (uint32_t i = 0; i < n_work; ++i) work[i * kWorkPad] = work_init;
   if (ext_override) st->rays[0] += ext_override;
   else if (n_ext) st->rays[0] += *n_ext;

@@ -498,7 +498,7 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     int by_regs = CASTER_TRACE_WAVES * 4 / kTraceBlockWaves * kTraceBlockWaves;
     r->walk_grid = r->n_cu * std::max(kTraceBlockWaves, std::min(by_lds, by_regs));
   }
-  r->work_init = ((uint32_t)r->walk_grid + kWorkShards - 1) / kWorkShards * kChunk;
+  r->work_init = 0;  // the work counters count from the end of k_trace's static assignment, whose size it derives from the queue length
   if (sc.integrator == IT_BDPT) {
     // one sample per lane at a time: as many wavefronts as are resident at once, within the
     // traversal grid (whose stack spill columns k_bdpt's lanes use)
