@@ -38,8 +38,9 @@ STAND_IN = {"car_pt": "bmw-m6 stand-in", "stairs_pt": "staircase2 stand-in", "kn
             "cornell_smoke": "Cornell box with a heterogeneous medium", "cornell_meshlight": "Cornell box with a mesh light"}
 
 
-def scene_path(name, detail, width, height, depth, rank, barrier):
-    """Generates the synthetic scene once per host (rank 0) and returns its path."""
+def scene_path(name, detail, width, height, depth, rank, barrier, integrator=None):
+    """Generates the synthetic scene once per host (rank 0) and returns its path.  `integrator`
+    renders the same scene with another of the reference's integrators (the "integrator" key)."""
     import gen_scenes
     tag = "%s_d%g_%dx%d_m%d" % (name, detail, width, height, depth)
     base = os.path.join(os.environ.get("CASTER_SCENE_CACHE", "/tmp/caster_scenes_%d" % os.getuid()), tag)
@@ -50,6 +51,16 @@ def scene_path(name, detail, width, height, depth, rank, barrier):
             os.rename(base + ".tmp%d" % os.getpid(), base)
         except OSError:
             pass  # another process won the race
+    if integrator:
+        other = os.path.join(base, "scene_%s.json" % integrator)
+        if rank == 0 and not os.path.exists(other):
+            with open(path) as f:
+                doc = json.load(f)
+            doc["integrator"] = integrator
+            with open(other + ".tmp%d" % os.getpid(), "w") as f:
+                json.dump(doc, f)
+            os.replace(other + ".tmp%d" % os.getpid(), other)
+        path = other
     barrier()
     return path
 
@@ -87,6 +98,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--integrator", default=None, help="render the scene with this integrator instead of its own (experiments)")
     ap.add_argument("--spp-per-step", type=int, default=192)
     ap.add_argument("--iters-in-flight", type=int, default=0, help="iterations per batch of paths (0: library default)")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams batches are dealt to (0: library default)")
@@ -118,7 +130,7 @@ def main():
             dist.barrier()
 
     caster = importlib.import_module("cuda-pathtracer_amd")
-    path = scene_path(a.scene, a.detail, a.width, a.height, a.depth, rank, barrier)
+    path = scene_path(a.scene, a.detail, a.width, a.height, a.depth, rank, barrier, a.integrator)
     scene = caster.Scene(path)
     spp = a.spp_per_step
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")

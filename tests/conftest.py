@@ -33,6 +33,10 @@ SMALL_SCENES = {
     "cornell_bdpt": dict(name="cornell_bdpt", width=96, height=96),
     "cornell_fog_bdpt": dict(name="cornell_fog_bdpt", width=96, height=96),
     "cornell_smoke_bdpt": dict(name="cornell_smoke_bdpt", width=96, height=96),
+    # the benchmark scene (all six materials, textures, lines and spheres) under the splatting integrators
+    "car_lt": dict(name="car_pt", width=96, height=54, detail=0.01, integrator="lt"),
+    "car_bdpt": dict(name="car_pt", width=96, height=54, detail=0.01, integrator="bdpt"),
+    "stairs_bdpt": dict(name="stairs_pt", width=64, height=36, detail=0.08, integrator="bdpt"),
     "knot_pt": dict(name="knot_pt", width=96, height=96, detail=0.08),
     "stairs_pt": dict(name="stairs_pt", width=128, height=72, detail=0.08),
     "car_pt": dict(name="car_pt", width=128, height=72, detail=0.01),
@@ -49,5 +53,11 @@ def scenes(tmp_path_factory):
     for key, kw in SMALL_SCENES.items():
         kw = dict(kw)
         name = kw.pop("name")
+        integrator = kw.pop("integrator", None)
         out[key] = gen_scenes.generate(str(base / key), name, **kw)
+        if integrator:   # the same scene under another of the reference's integrators
+            import json
+            doc = json.load(open(out[key]))
+            doc["integrator"] = integrator
+            json.dump(doc, open(out[key], "w"))
     return out

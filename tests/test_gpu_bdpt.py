@@ -16,7 +16,7 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 
-SPP = {"cornell_bdpt": 6, "cornell_fog_bdpt": 4, "cornell_smoke_bdpt": 4}
+SPP = {"cornell_bdpt": 6, "cornell_fog_bdpt": 4, "cornell_smoke_bdpt": 4, "car_bdpt": 4, "stairs_bdpt": 3}
 
 
 def rel(gpu, cpu):

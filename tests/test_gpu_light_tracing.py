@@ -14,7 +14,7 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 
-SPP = {"cornell_lt": 8, "cornell_fog_lt": 6, "cornell_smoke_lt": 6}
+SPP = {"cornell_lt": 8, "cornell_fog_lt": 6, "cornell_smoke_lt": 6, "car_lt": 6}
 
 
 def rel(gpu, cpu):
@@ -39,7 +39,7 @@ def test_first_hits_of_light_paths_bit_exact(caster, scenes, key):
     for it in (1, 5):
         cpu = o.primary_ids(it)
         gpu = r.primary_ids(it)
-        assert (cpu >= 0).mean() > 0.5   # most light paths reach the box (its front is open)
+        assert (cpu >= 0).mean() > (0.5 if key.startswith("cornell") else 0.05)   # most light paths reach the box (its front is open)
         assert np.array_equal(cpu, gpu), "%d of %d ids differ" % ((cpu != gpu).sum(), cpu.size)
     r.close()
 
@@ -61,7 +61,7 @@ def test_film_matches_oracle(caster, scenes, key):
     assert cpu.mean() > 1e-3 and gpu.mean() > 1e-3
     # light tracing leaves most of the film to indirect splats: the comparison is not one of a few bright pixels
     lit = float((cpu.max(axis=2) > 0).mean())   # (mirror and glass get no splats: Fr is zero for them)
-    assert lit > 0.75, lit
+    assert lit > (0.75 if key.startswith("cornell") else 0.05), lit
     check_close(gpu, cpu, key)
     # the transmittance walks of the camera connections, segment by segment
     assert st["rays"][3] == counts.as_dict()["rays"][3]
