@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Headless render of a scene file in the reference's JSON schema to an image.
+
+  python tools/render.py scene.json --spp 256 --out image.png
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+      tools/render.py scene.json --spp 4096 --shard spp --out image.exr
+
+One process per GPU.  With several ranks the iterations (``--shard spp``) or bands of scanlines
+(``--shard tile``) are split over the ranks (cuda-pathtracer_amd/sharding.py) and the films meet on
+rank 0 in one RCCL reduce, which then writes the image: .png is tonemapped as the reference's
+Output() + SavePng do, .exr and .pfm hold the linear mean.
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("scene")
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--out", default="render.png")
+    ap.add_argument("--shard", choices=["spp", "tile"], default="spp")
+    ap.add_argument("--gpu-bvh", action="store_true", help="build the BVH on the GPU (same tree as the host build)")
+    ap.add_argument("--iters-in-flight", type=int, default=0)
+    a = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    caster = importlib.import_module("cuda-pathtracer_amd")
+    sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    scene = caster.Scene(a.scene, build_device=dev if a.gpu_bvh else None)
+    r = caster.Renderer(scene, dev, a.iters_in_flight)
+    t0 = time.perf_counter()
+    if world > 1 and a.shard == "tile":
+        r.set_rows(*sharding.row_band(scene.height, rank, world))
+        blocks = [(1, a.spp)]
+    else:
+        block = max(1, min(64, a.spp // max(world, 1)))
+        blocks = sharding.spp_blocks(1, a.spp, block, rank, world)
+    first = True
+    for it, n in blocks:
+        r.render_async(it, n, first)
+        first = False
+    r.sync()
+    tonemapped = a.out.lower().endswith(".png")
+    if world == 1:
+        r.save_image(a.out)
+    else:
+        import torch
+        film = torch.zeros(scene.width * scene.height * 3, dtype=torch.float32, device="cuda:%d" % dev)
+        if not first:
+            r.read_film_device(film.data_ptr(), 2)
+        sharding.reduce_film(film, dist, 0)
+        if rank == 0:
+            # the summed film back into the renderer, which divides, tonemaps and writes it
+            r.render(1, 0, True)
+            r.film_add_device(film.data_ptr(), a.spp)
+            r.save_image(a.out)
+    if rank == 0:
+        dt = time.perf_counter() - t0
+        print("%s: %dx%d, %d spp on %d GPU(s) in %.2f s (%.1f Msamples/s) -> %s%s" % (
+            caster.INTEGRATOR_NAMES[scene.integrator], scene.width, scene.height, a.spp, world, dt,
+            scene.width * scene.height * a.spp / dt / 1e6, a.out, " (tonemapped)" if tonemapped else ""))
+    r.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
