@@ -28,10 +28,12 @@ def main():
     ap.add_argument("--shard", choices=["spp", "tile"], default="spp")
     ap.add_argument("--gpu-bvh", action="store_true", help="build the BVH on the GPU (same tree as the host build)")
     ap.add_argument("--iters-in-flight", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (gloo + --share-gpu rehearses N > 1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses device 0 (rehearsal only)")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     caster = importlib.import_module("cuda-pathtracer_amd")
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
     dist = None
@@ -39,7 +41,10 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(a.backend)
     scene = caster.Scene(a.scene, build_device=dev if a.gpu_bvh else None)
     r = caster.Renderer(scene, dev, a.iters_in_flight)
     t0 = time.perf_counter()
@@ -62,7 +67,12 @@ def main():
         film = torch.zeros(scene.width * scene.height * 3, dtype=torch.float32, device="cuda:%d" % dev)
         if not first:
             r.read_film_device(film.data_ptr(), 2)
-        sharding.reduce_film(film, dist, 0)
+        if a.backend == "nccl":
+            sharding.reduce_film(film, dist, 0)
+        else:  # films meet on the host
+            host = film.cpu()
+            sharding.reduce_film(host, dist, 0)
+            film.copy_(host)
         if rank == 0:
             # the summed film back into the renderer, which divides, tonemaps and writes it
             r.render(1, 0, True)
