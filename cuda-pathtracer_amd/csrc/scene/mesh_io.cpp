@@ -266,6 +266,233 @@ bool load_ppm(const std::string& data, Image8& im) {
   return true;
 }
 
+// Baseline (and extended sequential) Huffman JPEG, 8 bits, one or three components, sampling
+// factors 1 or 2, restart intervals: what the reference gets from stb_image for such a file
+// (imageio.cpp:12-17) up to the last bit of the inverse DCT and the colour conversion, which
+// differ between decoders (stb's are fixed-point; these are floating-point): parity unpinned to
+// +-1 level.  Progressive, arithmetic-coded, 12-bit and CMYK files are refused.
+struct JpegHuff {
+  uint8_t bits[17] = {0};
+  uint8_t vals[256] = {0};
+  int mincode[17] = {0}, maxcode[18] = {0}, valptr[17] = {0};
+  bool set = false;
+  void build() {
+    int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) {
+      valptr[l] = k;
+      mincode[l] = code;
+      code += bits[l];
+      k += bits[l];
+      maxcode[l] = bits[l] ? code - 1 : -1;
+      code <<= 1;
+    }
+    set = true;
+  }
+};
+struct JpegBits {
+  const uint8_t* p; size_t n, at;
+  uint32_t acc = 0; int cnt = 0; bool hit_marker = false;
+  int bit() {
+    if (cnt == 0) {
+      uint8_t b = 0;
+      if (!hit_marker && at < n) {
+        b = p[at++];
+        if (b == 0xff) {
+          uint8_t b2 = at < n ? p[at] : 0xd9;
+          if (b2 == 0) ++at;                       // a stuffed zero after a data byte 0xff
+          else { hit_marker = true; --at; b = 0; }  // a marker: the scan's data end here
+        }
+      }
+      acc = b; cnt = 8;
+    }
+    --cnt;
+    return (acc >> cnt) & 1;
+  }
+  int receive(int s) { int v = 0; for (int i = 0; i < s; ++i) v = (v << 1) | bit(); return v; }
+  void reset() { cnt = 0; hit_marker = false; }
+};
+inline int jpeg_extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+inline int jpeg_decode(JpegBits& br, const JpegHuff& h) {
+  int code = 0;
+  for (int l = 1; l <= 16; ++l) {
+    code = (code << 1) | br.bit();
+    if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+  }
+  return -1;
+}
+bool load_jpeg(const std::string& data, Image8& im, std::string& err) {
+  static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                                     41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                                     15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  const uint8_t* p = (const uint8_t*)data.data();
+  const size_t n = data.size();
+  if (n < 4 || p[0] != 0xff || p[1] != 0xd8) return false;
+  uint16_t qt[4][64] = {{0}};
+  JpegHuff hdc[4], hac[4];
+  struct Comp { int id, h, v, tq, td, ta, pred; int pw, ph; std::vector<uint8_t> plane; };
+  std::vector<Comp> comps;
+  int W = 0, H = 0, restart = 0;
+  size_t at = 2;
+  bool have_frame = false;
+  float cosv[8][8];
+  for (int x = 0; x < 8; ++x)
+    for (int u = 0; u < 8; ++u) cosv[x][u] = (u == 0 ? 0.70710678118654752f : 1.f) * cosf((2 * x + 1) * u * 3.14159265358979323846f / 16.f);
+  while (at + 4 <= n) {
+    if (p[at] != 0xff) { ++at; continue; }
+    uint8_t m = p[at + 1];
+    at += 2;
+    if (m == 0xd8 || m == 0x01 || (m >= 0xd0 && m <= 0xd7) || m == 0xff) { if (m == 0xff) --at; continue; }
+    if (m == 0xd9) break;
+    if (at + 2 > n) break;
+    size_t len = ((size_t)p[at] << 8) | p[at + 1];
+    if (len < 2 || at + len > n) { err = "truncated JPEG segment"; return false; }
+    const uint8_t* q = p + at + 2;
+    const uint8_t* qe = p + at + len;
+    if (m == 0xdb) {
+      while (q < qe) {
+        int pq = q[0] >> 4, tq = q[0] & 15;
+        ++q;
+        if (tq > 3 || q + (pq ? 128 : 64) > qe) { err = "bad JPEG quantisation table"; return false; }
+        for (int i = 0; i < 64; ++i) { qt[tq][i] = pq ? (uint16_t)((q[0] << 8) | q[1]) : q[0]; q += pq ? 2 : 1; }
+      }
+    } else if (m == 0xc4) {
+      while (q < qe) {
+        int tc = q[0] >> 4, th = q[0] & 15;
+        ++q;
+        if (tc > 1 || th > 3 || q + 16 > qe) { err = "bad JPEG Huffman table"; return false; }
+        JpegHuff& h = tc ? hac[th] : hdc[th];
+        int total = 0;
+        for (int l = 1; l <= 16; ++l) { h.bits[l] = q[l - 1]; total += q[l - 1]; }
+        q += 16;
+        if (total > 256 || q + total > qe) { err = "bad JPEG Huffman table"; return false; }
+        memcpy(h.vals, q, (size_t)total);
+        q += total;
+        h.build();
+      }
+    } else if (m == 0xc0 || m == 0xc1) {
+      if (qe - q < 6 || q[0] != 8) { err = "only 8-bit JPEG is supported"; return false; }
+      H = (q[1] << 8) | q[2]; W = (q[3] << 8) | q[4];
+      int nc = q[5];
+      if ((nc != 1 && nc != 3) || qe - q < 6 + 3 * nc || W <= 0 || H <= 0) { err = "JPEG with 1 or 3 components expected"; return false; }
+      comps.resize((size_t)nc);
+      for (int c = 0; c < nc; ++c) {
+        comps[c].id = q[6 + 3 * c]; comps[c].h = q[7 + 3 * c] >> 4; comps[c].v = q[7 + 3 * c] & 15; comps[c].tq = q[8 + 3 * c] & 3;
+        if (comps[c].h < 1 || comps[c].h > 2 || comps[c].v < 1 || comps[c].v > 2) { err = "JPEG sampling factors above 2 are not supported"; return false; }
+      }
+      have_frame = true;
+    } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
+      err = "progressive, lossless and arithmetic-coded JPEG files are not supported (baseline is)";
+      return false;
+    } else if (m == 0xdd) {
+      if (qe - q >= 2) restart = (q[0] << 8) | q[1];
+    } else if (m == 0xda) {
+      if (!have_frame) { err = "JPEG scan before its frame header"; return false; }
+      int ns = q[0];
+      if (ns != (int)comps.size() || qe - q < 1 + 2 * ns + 3) { err = "JPEG with one interleaved scan expected"; return false; }
+      for (int k = 0; k < ns; ++k) {
+        int id = q[1 + 2 * k];
+        bool ok = false;
+        for (auto& c : comps)
+          if (c.id == id) { c.td = q[2 + 2 * k] >> 4; c.ta = q[2 + 2 * k] & 15; ok = c.td < 4 && c.ta < 4 && hdc[c.td].set && hac[c.ta].set; }
+        if (!ok) { err = "bad JPEG scan header"; return false; }
+      }
+      int hmax = 1, vmax = 1;
+      for (auto& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+      if (comps.size() == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }
+      const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+      for (auto& c : comps) { c.pw = mcux * 8 * c.h; c.ph = mcuy * 8 * c.v; c.plane.assign((size_t)c.pw * c.ph, 0); c.pred = 0; }
+      JpegBits br{p, n, at + len};
+      int until_restart = restart;
+      for (int my = 0; my < mcuy; ++my)
+        for (int mx = 0; mx < mcux; ++mx) {
+          if (restart && until_restart == 0) {
+            // the restart marker follows the byte-aligned data of the interval
+            br.reset();
+            while (br.at + 1 < n && !(p[br.at] == 0xff && p[br.at + 1] >= 0xd0 && p[br.at + 1] <= 0xd7)) ++br.at;
+            br.at += 2;
+            for (auto& c : comps) c.pred = 0;
+            until_restart = restart;
+          }
+          --until_restart;
+          for (auto& c : comps)
+            for (int by = 0; by < c.v; ++by)
+              for (int bx = 0; bx < c.h; ++bx) {
+                float coef[64] = {0};
+                int t = jpeg_decode(br, hdc[c.td]);
+                if (t < 0 || t > 11) { err = "bad JPEG entropy data"; return false; }
+                c.pred += jpeg_extend(br.receive(t), t);
+                coef[0] = (float)(c.pred * qt[c.tq][0]);
+                for (int k = 1; k < 64;) {
+                  int rs = jpeg_decode(br, hac[c.ta]);
+                  if (rs < 0) { err = "bad JPEG entropy data"; return false; }
+                  int r = rs >> 4, sz = rs & 15;
+                  if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+                  k += r;
+                  if (k > 63) { err = "bad JPEG entropy data"; return false; }
+                  coef[zigzag[k]] = (float)(jpeg_extend(br.receive(sz), sz) * qt[c.tq][k]);
+                  ++k;
+                }
+                float tmp[64];
+                for (int y = 0; y < 8; ++y)      // rows
+                  for (int x = 0; x < 8; ++x) {
+                    float a = 0.f;
+                    for (int u = 0; u < 8; ++u) a += cosv[x][u] * coef[y * 8 + u];
+                    tmp[y * 8 + x] = a * 0.5f;
+                  }
+                uint8_t* dst = c.plane.data() + (size_t)((my * c.v + by) * 8) * c.pw + (size_t)(mx * c.h + bx) * 8;
+                for (int x = 0; x < 8; ++x)      // columns
+                  for (int y = 0; y < 8; ++y) {
+                    float a = 0.f;
+                    for (int v = 0; v < 8; ++v) a += cosv[y][v] * tmp[v * 8 + x];
+                    float val = a * 0.5f + 128.f;
+                    dst[(size_t)y * c.pw + x] = (uint8_t)(val < 0.f ? 0 : val > 255.f ? 255 : (int)(val + 0.5f));
+                  }
+              }
+        }
+      // chroma up to full resolution with a triangle filter (sample centres of a 2:1 plane sit
+      // between the luma samples), then YCbCr -> RGB
+      im.w = W; im.h = H; im.comp = (int)comps.size();
+      im.px.assign((size_t)W * H * im.comp, 0);
+      auto sample = [&](const Comp& c, int x, int y) -> float {
+        auto at1 = [](int i, int f, int lim, float& w) -> int {   // position of full-res index i in a plane subsampled by f
+          if (f == 1) { w = 0.f; return i; }
+          float pos = (i + 0.5f) / f - 0.5f;
+          int i0 = (int)floorf(pos);
+          w = pos - i0;
+          (void)lim;
+          return i0;
+        };
+        int fx = hmax / c.h, fy = vmax / c.v;
+        float wx, wy;
+        int x0 = at1(x, fx, c.pw, wx), y0 = at1(y, fy, c.ph, wy);
+        int cw = (W + fx - 1) / fx, chh = (H + fy - 1) / fy;
+        auto px = [&](int xx, int yy) -> float {
+          xx = xx < 0 ? 0 : xx >= cw ? cw - 1 : xx;
+          yy = yy < 0 ? 0 : yy >= chh ? chh - 1 : yy;
+          return (float)c.plane[(size_t)yy * c.pw + xx];
+        };
+        if (fx == 1 && fy == 1) return px(x0, y0);
+        return (1 - wy) * ((1 - wx) * px(x0, y0) + wx * px(x0 + 1, y0)) + wy * ((1 - wx) * px(x0, y0 + 1) + wx * px(x0 + 1, y0 + 1));
+      };
+      auto clamp8 = [](float v) -> uint8_t { return (uint8_t)(v < 0.f ? 0 : v > 255.f ? 255 : (int)(v + 0.5f)); };
+      for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+          uint8_t* o = im.px.data() + ((size_t)y * W + x) * im.comp;
+          float Y = sample(comps[0], x, y);
+          if (im.comp == 1) { o[0] = clamp8(Y); continue; }
+          float cb = sample(comps[1], x, y) - 128.f, cr = sample(comps[2], x, y) - 128.f;
+          o[0] = clamp8(Y + 1.402f * cr);
+          o[1] = clamp8(Y - 0.344136f * cb - 0.714136f * cr);
+          o[2] = clamp8(Y + 1.772f * cb);
+        }
+      return true;
+    }
+    at += len;
+  }
+  err = "JPEG file without image data";
+  return false;
+}
+
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
 
 // Non-interlaced 8-bit grey / RGB / RGBA PNG.
@@ -343,7 +570,8 @@ bool load_texture_file(const std::string& path, Texture& out, std::string& err) 
   Image8 im;
   if (!load_ppm(data, im)) {
     std::string perr;
-    if (!load_png(data, im, perr)) { err = "texture \"" + path + "\": " + perr; return false; }
+    const bool jpeg = data.size() > 2 && (uint8_t)data[0] == 0xff && (uint8_t)data[1] == 0xd8;
+    if (jpeg ? !load_jpeg(data, im, perr) : !load_png(data, im, perr)) { err = "texture \"" + path + "\": " + perr; return false; }
   }
   out.w = im.w; out.h = im.h;
   out.rgba.resize((size_t)im.w * im.h * 4);

@@ -1955,6 +1955,14 @@ void oracle_info(const oracle_ctx* c, int* o) {
   o[7] = s.maxDepth;
 }
 
+int oracle_texture(const oracle_ctx* c, int idx, int* wh, unsigned char* rgba) {
+  const Scene& s = c->cx.scene;
+  if (idx < 0 || idx >= (int)s.textures.size()) return 1;
+  wh[0] = s.textures[(size_t)idx].w; wh[1] = s.textures[(size_t)idx].h;
+  if (rgba) memcpy(rgba, s.textures[(size_t)idx].rgba.data(), s.textures[(size_t)idx].rgba.size());
+  return 0;
+}
+
 int oracle_render(oracle_ctx* c, uint32_t first_iter, uint32_t n_iter, int threads, float* acc,
                   oracle_counts* counts) {
   return oracle_render_rows(c, first_iter, n_iter, threads, 0, c->cx.scene.height, acc, counts);

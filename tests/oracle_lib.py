@@ -54,6 +54,7 @@ def lib():
         L.oracle_trace.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float, fp]
         L.oracle_occluded.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float]
         L.oracle_sample_camera.argtypes = [C.c_void_p, fp, fp]
+        L.oracle_texture.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]
         L.oracle_bsdf_sample.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, fp, fp]
         L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp, fp, fp]
         L.oracle_light_sample.argtypes = [C.c_void_p, C.c_int, fp, fp, fp]
@@ -130,6 +131,15 @@ class Oracle:
 
     def occluded(self, origin, direction, tmin=1e-3, tmax=np.inf):
         return bool(self.L.oracle_occluded(self.h, _fp(_f32(origin)), _fp(_f32(direction)), tmin, tmax))
+
+    def texture(self, idx):
+        """Texture `idx` as loaded: (h, w, 4) uint8, row 0 = bottom."""
+        wh = (C.c_int * 2)()
+        if self.L.oracle_texture(self.h, idx, wh, None) != 0:
+            raise IndexError(idx)
+        out = np.empty((wh[1], wh[0], 4), np.uint8)
+        self.L.oracle_texture(self.h, idx, wh, out.ctypes.data_as(C.c_void_p))
+        return out
 
     def sample_camera(self, pos):
         """(raster index or -1, [importance, pdf, tmax])"""

@@ -333,3 +333,46 @@ def test_obj_without_normals_gets_smooth_ones(caster, tmp_path):
     with pytest.raises(caster.CasterError, match="with and faces without normals"):
         caster.Scene(write_scene(tmp_path, {"camera": {}, "material": [{"name": "m", "bsdf": "mirror"}],
                                             "scene": [{"mesh": "x.obj", "material": "m"}]}, [("x.obj", mixed)]))
+
+
+@pytest.mark.parametrize("subsampling,quality,mode,restart", [(0, 92, "RGB", 0), (2, 85, "RGB", 0), (1, 90, "RGB", 4), (0, 90, "L", 0)])
+def test_jpeg_textures(tmp_path, subsampling, quality, mode, restart):
+    """The reference loads textures through stb_image, JPEG included (imageio.cpp:12-17).  A baseline
+    JPEG texture decodes to what Pillow makes of the same file, to the +-1 or 2 levels by which
+    decoders differ in their inverse DCT, chroma filter and colour conversion."""
+    from PIL import Image
+    import oracle_lib as ol
+    rng = np.random.RandomState(5)
+    w, h = 52, 37                                                   # not multiples of the MCU size
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(xx / 7.0), 128 + 90 * np.cos(yy / 5.0), 60 + 2.5 * xx + yy], axis=2)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    pil = Image.fromarray(img if mode == "RGB" else img[:, :, 0], mode)
+    kw = dict(quality=quality, subsampling=subsampling) if mode == "RGB" else dict(quality=quality)
+    if restart:
+        kw["restart_marker_blocks"] = restart
+    pil.save(str(tmp_path / "t.jpg"), "JPEG", **kw)
+    Image.open(str(tmp_path / "t.jpg")).convert("RGB").save(str(tmp_path / "t.png"))
+    tex = {}
+    for ext in ("jpg", "png"):
+        doc = {"camera": {}, "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "t." + ext}],
+               "scene": [{"mesh": "q.obj", "material": "m"}]}
+        d = tmp_path / ext
+        d.mkdir()
+        for f in ("t." + ext,):
+            (d / f).write_bytes((tmp_path / f).read_bytes())
+        tex[ext] = ol.Oracle(write_scene(d, doc, [("q.obj", QUAD)])).texture(0).astype(np.int32)
+    assert tex["jpg"].shape == (h, w, 4)
+    # compare before the sRGB -> linear step amplifies a level at the bright end: undo it approximately
+    diff = np.abs(tex["jpg"][:, :, :3] - tex["png"][:, :, :3])
+    assert diff.mean() < (1.0 if subsampling == 0 else 2.0), diff.mean()
+    assert np.percentile(diff, 99) <= (4 if subsampling == 0 else 10), np.percentile(diff, 99)
+
+
+def test_progressive_jpeg_is_refused(caster, tmp_path):
+    from PIL import Image
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(str(tmp_path / "p.jpg"), "JPEG", progressive=True)
+    doc = {"camera": {}, "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "p.jpg"}],
+           "scene": [{"mesh": "q.obj", "material": "m"}]}
+    with pytest.raises(caster.CasterError, match="progressive"):
+        caster.Scene(write_scene(tmp_path, doc, [("q.obj", QUAD)]))
