@@ -2582,19 +2582,26 @@ __device__ __noinline__ float bdpt_mis(const BdptStore& V, uint32_t g, int s, in
   return 1.f / (sumW + 1.f);
 }
 
-// Phase function or BSDF of a sub-path vertex with its density, as Connect() picks between them.
-__device__ __noinline__ void bdpt_vertex_fr(const DevScene& S, bool use_medium, const BVert& v, V3 in, V3 out, V3& fr, float& pdf) {
+// Phase function or BSDF of a sub-path vertex with its density, as Connect() picks between them,
+// for the pair of directions (in, out) and, for the density only, the reversed pair (out, in):
+// Connect() asks for both at every vertex it joins (:1767/1785, :1820/1833, :1876-1896), and the
+// material is fetched once for the two.
+__device__ __noinline__ void bdpt_vertex_fr(const DevScene& S, bool use_medium, const BVert& v, V3 in, V3 out, V3& fr, float& pdf,
+                                            float& rpdf) {
   if (use_medium) {
     MediumRec med;
     load_medium(S, v.medium, med);
     float phase = phase_eval(med, in, out);
     pdf = phase;
     fr = v3(phase, phase, phase);
+    rpdf = phase_eval(med, out, in);
   } else {
     Mat m;
     load_mat(S, v.mat, m);
     resolve_texture(S, m, v.uv);
     eval_bsdf(S, m, in, out, v.n, v.uv, v.dpdu, fr, pdf);
+    V3 unuse;
+    eval_bsdf(S, m, out, in, v.n, v.uv, v.dpdu, unuse, rpdf);
   }
 }
 
@@ -2651,8 +2658,8 @@ __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const Bdp
     V3 tr = transmittance(S, cur.pos, sdir, eps, stmax, cur.medium, st, stats, n_tr, rng);
     if (is_black(tr)) return zero;
     V3 fr;
-    float nextPdf;
-    bdpt_vertex_fr(S, isMedium, cur, in, sdir, fr, nextPdf);
+    float nextPdf, pdf;
+    bdpt_vertex_fr(S, isMedium, cur, in, sdir, fr, nextPdf, pdf);
     float G = isMedium ? 1.f : fabsf(dot(cur.n, sdir));
     V3 Lr = zero + cur.beta * tr * fr * radiance * G / (lightPdf * choicePdf);
     if (is_black(Lr)) return zero;
@@ -2661,8 +2668,6 @@ __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const Bdp
     float next_fwd = pdfA * choicePdf;
     float next_rev = convert_pdf(nextPdf, cur.pos, lightPos, lightNor);
     float cur_rev = convert_pdf(pdfW, lightPos, cur.pos, cur.n);
-    float pdf;
-    bdpt_vertex_fr(S, isMedium, cur, sdir, in, fr, pdf);
     float prev_rev = convert_pdf(pdf, cur.pos, prev_pos, prev_n);
     float mis = bdpt_mis(V, g, s, t, cur_rev, prev_rev, next_rev, 0.f, next_fwd);
     return mis * Lr;
@@ -2682,16 +2687,14 @@ __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const Bdp
     V3 tr = transmittance(S, cur.pos, sdir, eps, stmax, cur.medium, st, stats, n_tr, rng);
     if (is_black(tr)) return zero;
     V3 fr;
-    float nextPdf, costheta = fabsf(dot(sdir, cur.n));
-    bdpt_vertex_fr(S, isMedium, cur, in, sdir, fr, nextPdf);
+    float nextPdf, pdf, costheta = fabsf(dot(sdir, cur.n));
+    bdpt_vertex_fr(S, isMedium, cur, in, sdir, fr, nextPdf, pdf);
     if (isMedium) costheta = 1.f;
     V3 Lr = zero + cur.beta * tr * fr * we * costheta / cameraPdf;
     if (is_black(Lr)) return zero;
     V3 cam_pos = v3(S.cam.pos), cam_n = -v3(S.cam.w);
     float pdfW = pdf_camera_w(S.cam, -sdir);
     float cur_rev = convert_pdf(pdfW, cam_pos, cur.pos, cur.n);
-    float pdf;
-    bdpt_vertex_fr(S, isMedium, cur, sdir, in, fr, pdf);
     float prev_rev = convert_pdf(pdf, cur.pos, prev_pos, prev_n);
     (void)cam_n;  // cameraPath[0].rev is written by the reference here and never read by MisWeight
     float mis = bdpt_mis(V, g, s, t, 0.f, 0.f, cur_rev, prev_rev, 0.f);
@@ -2719,17 +2722,14 @@ __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const Bdp
   float cos1 = l1Med ? 1.f : fabsf(dot(l1Toc1, l1.n));
   float cos2 = c1Med ? 1.f : fabsf(dot(c1Tol1, c1.n));
   V3 c1Fr, l1Fr;
-  float l1Pdf, c1Pdf;
-  bdpt_vertex_fr(S, c1Med, c1, c1Toc2, c1Tol1, c1Fr, l1Pdf);
-  bdpt_vertex_fr(S, l1Med, l1, l1Tol2, l1Toc1, l1Fr, c1Pdf);
+  float l1Pdf, c1Pdf, l2Pdf, c2Pdf;
+  bdpt_vertex_fr(S, c1Med, c1, c1Toc2, c1Tol1, c1Fr, l1Pdf, c2Pdf);
+  bdpt_vertex_fr(S, l1Med, l1, l1Tol2, l1Toc1, l1Fr, c1Pdf, l2Pdf);
   V3 G = tr * cos1 * cos2 / dot(dir, dir);
   V3 Lr = zero + c1.beta * c1Fr * G * l1Fr * l1.beta;
   if (is_black(Lr)) return zero;
   float c1_rev = convert_pdf(c1Pdf, l1.pos, c1.pos, c1.n);
   float l1_rev = convert_pdf(l1Pdf, c1.pos, l1.pos, l1.n);
-  float l2Pdf, c2Pdf;
-  bdpt_vertex_fr(S, l1Med, l1, l1Toc1, l1Tol2, l1Fr, l2Pdf);
-  bdpt_vertex_fr(S, c1Med, c1, c1Tol1, c1Toc2, c1Fr, c2Pdf);
   float l2_rev = convert_pdf(l2Pdf, l1.pos, l2_pos, l2_n);
   float c2_rev = convert_pdf(c2Pdf, c1.pos, c2_pos, c2_n);
   float mis = bdpt_mis(V, g, s, t, c1_rev, c2_rev, l1_rev, l2_rev, 0.f);
