@@ -2061,9 +2061,11 @@ __device__ inline void sample_camera(const DevScene& S, V3 pos, V3& sdir, float&
 }
 __device__ inline void splat(const DevScene& S, float* acc, int raster, V3 v) {
   if (raster < 0 || raster >= S.width * S.height) return;  // a NaN position
-  unsafeAtomicAdd(acc + 3 * (size_t)raster, v.x);
-  unsafeAtomicAdd(acc + 3 * (size_t)raster + 1, v.y);
-  unsafeAtomicAdd(acc + 3 * (size_t)raster + 2, v.z);
+  // adding a zero changes nothing (the sums start at +0), and a third to a half of all connections
+  // are occluded or face away from the camera: their atomics are not issued
+  if (v.x != 0.f) unsafeAtomicAdd(acc + 3 * (size_t)raster, v.x);
+  if (v.y != 0.f) unsafeAtomicAdd(acc + 3 * (size_t)raster + 1, v.y);
+  if (v.z != 0.f) unsafeAtomicAdd(acc + 3 * (size_t)raster + 2, v.z);
 }
 // Medium::Sample (medium.h:18-38 homogeneous, :81-109 delta tracking): scales beta, reports a
 // scattering event before the surface at rtmax.
@@ -2137,14 +2139,29 @@ __device__ inline V3 phase_sample(const MediumRec& med, float ux, float uy) {
 // A path that picks no emissive triangle (none in the scene, or the environment's bin, where the
 // reference reads past its light array) draws its numbers and carries nothing.  `acc` null: no
 // connection, only the rays (for the first-hit map).
+// QUEUED (scenes without a density grid, where Tr() draws no random numbers): a connection is not
+// walked here but sent through the traversal kernel -- its ray goes to `conn.shadow`, the path's
+// slot to the list `conn.probe`, the operands of its contribution to pend_x / pend_y / pend_z, and
+// k_lt_resolve splats it once k_tr_step / k_tr_finish have left its transmittance in pend_w.
+struct LtConn {
+  RayQueue shadow, probe;  // final queues
+  StageArea stage;
+};
+enum { kLtSurface = 0, kLtMedium = 1, kLtStart = 2 };
+template <bool QUEUED>
 __global__ __launch_bounds__(kWave) void k_generate_lt(LaunchCtx L, RayQueue q, uint32_t first_iter, uint32_t n_iter,
-                                                       int y0, int y1, float* acc, WalkAux aux) {
+                                                       int y0, int y1, float* acc, WalkAux aux, LtConn conn) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
   Stack st{s_stack, aux.spill + (blockIdx.x * kWave + threadIdx.x), aux.spill_stride, 0};
   const DevScene& S = L.S;
   uint32_t stat_tr = 0;
-  uint32_t total = (uint32_t)S.slots_per_iter * n_iter;
+  uint32_t total = (uint32_t)S.slots_per_iter * n_iter;  // a multiple of the wavefront size
+  const uint32_t sbase = blockIdx.x * conn.stage.region_cap;
+  uint32_t n_conn = 0, n_list = 0;
   for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < total; idx += gridDim.x * kWave) {
+    bool want_conn = false;
+    V3 co = v3(0, 0, 0), cd = v3(0, 0, 1);
+    float ctm = 0.f;
     uint32_t k, local;
     batch_slot_split(S, idx, n_iter, k, local);
     uint32_t px, py;
@@ -2183,8 +2200,16 @@ __global__ __launch_bounds__(kWave) void k_generate_lt(LaunchCtx L, RayQueue q, 
           int raster = 0;
           sample_camera(S, pos, cdir, ctmax, we, cameraPdf, raster);
           if (cameraPdf != 0.f) {
-            V3 tr = transmittance(S, pos, cdir, S.epsilon, ctmax, lmed, st, L.stats, stat_tr, rng);
-            if (!is_black(tr)) splat(S, acc, raster, tr * l.radiance);
+            if (QUEUED) {
+              want_conn = true;
+              co = pos; cd = cdir; ctm = ctmax;
+              L.P.pend_x[idx] = f4(l.radiance, 0.f);
+              L.P.pend_z[idx] = make_float4(cameraPdf, __int_as_float(raster), __int_as_float(kLtStart), 0.f);
+              L.P.pend_w[idx] = f4(v3(1.f, 1.f, 1.f), (uint32_t)lmed);
+            } else {
+              V3 tr = transmittance(S, pos, cdir, S.epsilon, ctmax, lmed, st, L.stats, stat_tr, rng);
+              if (!is_black(tr)) splat(S, acc, raster, tr * l.radiance);
+            }
           }
         }
         o4 = f4(pos, __int_as_float(-1));
@@ -2198,12 +2223,22 @@ __global__ __launch_bounds__(kWave) void k_generate_lt(LaunchCtx L, RayQueue q, 
     L.P.beta_rng[idx] = f4(beta, rng);
     L.P.li_flags[idx] = f4(v3(0.f, 0.f, 0.f), flags);
     L.P.beta_prev[idx] = make_float4(0, 0, 0, 0);
+    if (QUEUED) {
+      stage_push(conn.stage.shadow, sbase, n_conn, want_conn, (int)idx, co, -1, cd, ctm);
+      stage_push(conn.stage.probe, sbase, n_list, want_conn, (int)idx, co, -1, cd, ctm);
+    }
+  }
+  if (QUEUED) {
+    __syncthreads();
+    stage_flush(conn.stage.shadow, sbase, n_conn, conn.shadow);
+    stage_flush(conn.stage.probe, sbase, n_list, conn.probe);
   }
   for (int off = 32; off > 0; off >>= 1) stat_tr += (uint32_t)__shfl_down((int)stat_tr, off, 64);
   if ((threadIdx.x & 63u) == 0 && stat_tr) atomicAdd(&L.stats->rays[3], (unsigned long long)stat_tr);
 }
 
 // One event of a light path (pathtracer.cu:1275-1374).
+template <bool QUEUED>
 __global__ __launch_bounds__(kWave) void k_shade_lt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage,
                                                     WalkAux aux, float* acc) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
@@ -2215,12 +2250,13 @@ __global__ __launch_bounds__(kWave) void k_shade_lt(LaunchCtx L, RayQueue cur, S
   uint32_t r0, r1;
   wave_rounds(count, r0, r1);
   const uint32_t sbase = blockIdx.x * stage.region_cap;
-  uint32_t n_next = 0;
+  uint32_t n_next = 0, n_conn = 0, n_list = 0;
   for (uint32_t r = r0; r < r1; ++r) {
     uint32_t idx = r * kWave + threadIdx.x;
-    bool want_next = false;
+    bool want_next = false, want_conn = false;
     int slot = 0;
-    V3 no = v3(0, 0, 0), nd = v3(0, 0, 1);
+    V3 no = v3(0, 0, 0), nd = v3(0, 0, 1), co = no, cd = nd;
+    float ctm = 0.f;
     if (idx < count) {
       slot = cur.slot[idx];
       float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
@@ -2263,7 +2299,16 @@ __global__ __launch_bounds__(kWave) void k_shade_lt(LaunchCtx L, RayQueue cur, S
             // the reference walks Tr() whatever the camera sees (pathtracer.cu:1299); the walk draws
             // random numbers only inside a density grid, so without one a connection that cannot
             // contribute skips it
-            if (cameraPdf != 0.f || S.has_hetero) {
+            if (QUEUED) {
+              if (cameraPdf != 0.f) {
+                want_conn = true;
+                co = samplePos; cd = cdir; ctm = ctmax;
+                P.pend_x[slot] = f4(beta, we);
+                P.pend_y[slot] = make_float4(phase_eval(med, -rd, cdir), 0.f, 0.f, 0.f);
+                P.pend_z[slot] = make_float4(cameraPdf, __int_as_float(raster), __int_as_float(kLtMedium), 0.f);
+                P.pend_w[slot] = f4(v3(1.f, 1.f, 1.f), (uint32_t)rmed);
+              }
+            } else if (cameraPdf != 0.f || S.has_hetero) {
               V3 tr = transmittance(S, samplePos, cdir, S.epsilon, ctmax, rmed, st, L.stats, stat_tr, rng);
               float phase = phase_eval(med, -rd, cdir);
               if (cameraPdf != 0.f) {
@@ -2289,12 +2334,22 @@ __global__ __launch_bounds__(kWave) void k_shade_lt(LaunchCtx L, RayQueue cur, S
               int raster = 0;
               sample_camera(S, pos, cdir, ctmax, we, cameraPdf, raster);
               if (cameraPdf != 0.f) {
-                V3 tr = transmittance(S, pos, cdir, S.epsilon, ctmax, rmed, st, L.stats, stat_tr, rng);
                 V3 fr;
                 float unuse;
-                eval_bsdf(S, m, -rd, cdir, nor, uv, dpdu, fr, unuse);
-                V3 Lc = tr * beta * fr * we * fabsf(dot(cdir, nor)) / cameraPdf;
-                if (!has_inf(Lc) && !has_nan(Lc)) splat(S, acc, raster, Lc);
+                if (QUEUED) {
+                  eval_bsdf(S, m, -rd, cdir, nor, uv, dpdu, fr, unuse);
+                  want_conn = true;
+                  co = pos; cd = cdir; ctm = ctmax;
+                  P.pend_x[slot] = f4(beta, we);
+                  P.pend_y[slot] = f4(fr, fabsf(dot(cdir, nor)));
+                  P.pend_z[slot] = make_float4(cameraPdf, __int_as_float(raster), __int_as_float(kLtSurface), 0.f);
+                  P.pend_w[slot] = f4(v3(1.f, 1.f, 1.f), (uint32_t)rmed);
+                } else {
+                  V3 tr = transmittance(S, pos, cdir, S.epsilon, ctmax, rmed, st, L.stats, stat_tr, rng);
+                  eval_bsdf(S, m, -rd, cdir, nor, uv, dpdu, fr, unuse);
+                  V3 Lc = tr * beta * fr * we * fabsf(dot(cdir, nor)) / cameraPdf;
+                  if (!has_inf(Lc) && !has_nan(Lc)) splat(S, acc, raster, Lc);
+                }
               }
             }
             V3 u;
@@ -2332,11 +2387,43 @@ __global__ __launch_bounds__(kWave) void k_shade_lt(LaunchCtx L, RayQueue cur, S
       }
     }
     stage_push(stage.next, sbase, n_next, want_next, slot, no, -1, nd, INFINITY);
+    if (QUEUED) {
+      stage_push(stage.shadow, sbase, n_conn, want_conn, slot, co, -1, cd, ctm);
+      stage_push(stage.probe, sbase, n_list, want_conn, slot, co, -1, cd, ctm);
+    }
   }
   __syncthreads();
   stage_flush(stage.next, sbase, n_next, out.next);
+  if (QUEUED) {
+    stage_flush(stage.shadow, sbase, n_conn, out.shadow);
+    stage_flush(stage.probe, sbase, n_list, out.probe);
+  }
   for (int off = 32; off > 0; off >>= 1) stat_tr += (uint32_t)__shfl_down((int)stat_tr, off, 64);
   if ((threadIdx.x & 63u) == 0 && stat_tr) atomicAdd(&L.stats->rays[3], (unsigned long long)stat_tr);
+}
+
+// The connections of one round of light tracing on queues, their transmittance known: the same
+// products, in the same order, as the in-kernel path above forms (pathtracer.cu:1271, 1303, 1343).
+__global__ __launch_bounds__(kWave) void k_lt_resolve(LaunchCtx L, RayQueue list, float* acc) {
+  const DevScene& S = L.S;
+  const PathState& P = L.P;
+  const uint32_t count = *list.count;
+  for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
+    int slot = list.slot[idx];
+    float4 a = P.pend_x[slot], c = P.pend_z[slot];
+    V3 tr = v3(P.pend_w[slot]);
+    int raster = __float_as_int(c.y), kind = __float_as_int(c.z);
+    float cameraPdf = c.x;
+    if (kind == kLtStart) {
+      if (!is_black(tr)) splat(S, acc, raster, tr * v3(a));
+      continue;
+    }
+    float4 b = P.pend_y[slot];
+    V3 beta = v3(a);
+    float we = a.w;
+    V3 Lc = kind == kLtMedium ? beta * we * tr * b.x / cameraPdf : tr * beta * v3(b) * we * b.w / cameraPdf;
+    if (!has_inf(Lc) && !has_nan(Lc)) splat(S, acc, raster, Lc);
+  }
 }
 
 // ---- bidirectional path tracing ---------------------------------------------------
