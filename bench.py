@@ -66,7 +66,7 @@ def scene_path(name, detail, width, height, depth, rank, barrier, integrator=Non
 
 
 def algorithmic_bytes_per_ray(counts, kind):
-    """SURVEY-defined per-ray traversal bytes from the oracle's visit counts."""
+    """Algorithmic per-ray traversal bytes (32 B per node visited, 36 B per triangle, 16 B per sphere, 32 B per line tested) from the oracle's visit counts."""
     rays = counts["rays"][kind]
     if rays == 0:
         return 0.0
@@ -266,7 +266,7 @@ def main():
                    shade_name: (("shade", None),)}
 
         def algorithmic_bytes(sym, rays_now):
-            """SURVEY-defined bytes the launches of `sym` had to move for `rays_now` = this rank's ray
+            """Algorithmic bytes the launches of `sym` had to move for `rays_now` = this rank's ray
             counts [extension, shadow, probe, transmittance]."""
             if counts is None:
                 return None
