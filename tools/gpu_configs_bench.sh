@@ -1,4 +1,4 @@
-# throughput of all five benchmark configurations (only C5 is the bench line; the others are reported in profiles/README.md)
+# throughput of all five benchmark configurations (only the car scene is the bench line)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 : > gpurun_out/configs.txt
