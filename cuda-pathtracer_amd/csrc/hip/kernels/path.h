@@ -1,0 +1,371 @@
+// Part of the gfx950 wavefront renderer (included by ../kernels.hip, in this order: common.h, traverse.h, trace.h, shading.h, path.h, volpath.h, lighttrace.h, bdpt.h, volpath_queues.h, film.h).
+// Queue staging, the path-tracing vertex (k_shade_pt), its probe resolution, the AO vertex.
+#pragma once
+
+namespace caster {
+
+// Queues a path writes to while being shaded.
+struct ShadeQueues {
+  RayQueue next;    // continuation rays (closest hit)
+  RayQueue shadow;  // light-sample rays (any hit)
+  RayQueue probe;   // BSDF-sampled direct-light rays (closest hit + weighting)
+};
+
+// Two-level queue compaction.  A shading wavefront appends the rays it emits,
+// ballot-compacted, to a staging region of its own (no atomics: the cursor is
+// a wave-uniform register), and when it has shaded all its paths it reserves
+// its final range in the shared queue with ONE atomic per queue and copies the
+// region there.  Appending straight to the shared queue costs one same-address
+// atomic per 64 paths per queue, which is what bounded the shade stage before.
+struct StageArea {
+  RayQueue next, shadow, probe;  // o/d/slot arrays of gridDim.x * region_cap entries; count unused
+  uint32_t region_cap;           // entries per wavefront region
+};
+__device__ inline void stage_push(const RayQueue& stage, uint32_t base, uint32_t& n, bool want, int slot, V3 o,
+                                  int seed, V3 d, float tmax) {
+  unsigned long long mask = __ballot(want);
+  if (mask == 0) return;
+  uint32_t lane = threadIdx.x & 63u;
+  if (want) {
+    uint32_t at = base + n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    stage.o[at] = f4(o, __int_as_float(seed));
+    stage.d[at] = f4(d, tmax);
+    stage.slot[at] = slot;
+  }
+  n += (uint32_t)__popcll(mask);
+}
+__device__ inline void stage_flush(const RayQueue& stage, uint32_t base, uint32_t n, const RayQueue& fin) {
+  n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+  if (n == 0) return;
+  uint32_t lane = threadIdx.x & 63u;
+  uint32_t off = 0;
+  if (lane == 0) off = atomicAdd(fin.count, n);
+  off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+  for (uint32_t i = lane; i < n; i += kWave) {
+    fin.o[off + i] = stage.o[base + i];
+    fin.d[off + i] = stage.d[base + i];
+    fin.slot[off + i] = stage.slot[base + i];
+  }
+}
+// The rounds (groups of 64 queue entries) wavefront `blockIdx.x` shades: a
+// contiguous range, so that the compacted output keeps the input's order.
+__device__ inline void wave_rounds(uint32_t count, uint32_t& r0, uint32_t& r1) {
+  uint32_t rounds = (count + kWave - 1) / kWave;
+  uint32_t per = (rounds + gridDim.x - 1) / gridDim.x;
+  r0 = blockIdx.x * per;
+  r1 = r0 + per < rounds ? r0 + per : rounds;
+}
+
+// Adds the two direct-light terms left pending by the previous vertex:
+// Li += beta * (Ld_light + Ld_bsdf)  (pathtracer.cu:984).
+__device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li, uint32_t flags) {
+  V3 x = v3(P.pend_x[slot]);
+  V3 y = (flags & kFPendingY) ? v3(P.pend_y[slot]) : v3(0.f, 0.f, 0.f);
+  V3 bp = v3(P.beta_prev[slot]);
+  V3 Ld = x + y;
+  return Li + bp * Ld;
+}
+
+// One vertex of Path() (pathtracer.cu:897-1007) for every path whose
+// extension ray has been traced.
+#ifndef CASTER_SHADE_WAVES
+#define CASTER_SHADE_WAVES 4
+#endif
+#ifndef CASTER_PROBE_CULL
+#define CASTER_PROBE_CULL 1
+#endif
+constexpr int kProbeCullLights = 8;  // emitter triangles tested directly before a probe ray is sent
+__global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
+  const DevScene& S = L.S;
+  const PathState& P = L.P;
+  const uint32_t count = *cur.count;
+  uint32_t r0, r1;
+  wave_rounds(count, r0, r1);
+  const uint32_t sbase = blockIdx.x * stage.region_cap;
+  uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
+  for (uint32_t r = r0; r < r1; ++r) {
+    uint32_t idx = r * kWave + threadIdx.x;
+    bool active = idx < count;
+    int slot = 0;
+    bool want_next = false, want_shadow = false, want_probe = false;
+    V3 no = v3(0, 0, 0), nd = v3(0, 0, 1), so = no, sd = nd, po = no, pd = nd;
+    float stmax = 0.f, ptmax = INFINITY;
+    int pseed = -1;
+    if (active) {
+      slot = cur.slot[idx];
+      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+      active = d4.w >= 0.f || __float_as_int(h4.y) >= 0;
+      if (!active) {
+        // slot outside the image: nothing to do, it never contributes
+      }
+    }
+    if (active) {
+      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+      V3 ro = v3(o4), rd = v3(d4);
+      Hit h;
+      h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+      float4 br = P.beta_rng[slot], lf = P.li_flags[slot];
+      V3 beta = v3(br), Li = v3(lf);
+      uint32_t rng = __float_as_uint(br.w), flags = __float_as_uint(lf.w);
+      int bounces = (int)(flags & kFBounceMask);
+      bool specular = (flags & kFSpecular) != 0;
+      if (flags & kFPending) {
+        Li = resolve_pending(P, slot, Li, flags);
+        flags &= ~(kFPending | kFPendingY);
+      }
+      bool alive = true;
+      if (h.prim < 0) {
+        if ((bounces == 0 || specular) && S.inf.valid) Li = Li + beta * inf_le(S.inf, rd);
+        alive = false;
+      }
+      if (alive) {
+        Isect is;
+        load_isect(S, ro, rd, h, is);
+        V3 pos = is.pos, nor = is.n, dpdu = is.dpdu;
+        V2 uv = is.uv;
+        Mat m;
+        load_mat(S, is.mat, m);
+        resolve_texture(S, m, uv);
+        if ((bounces == 0 || specular) && is.light != -1) {
+          // Area::Le (area.h:36-39)
+          LightRec l;
+          load_light(S, is.light, l);
+          V3 le = dot(nor, -rd) > 0.f ? l.radiance : v3(0, 0, 0);
+          Li = Li + beta * le;
+          alive = false;
+        }
+        if (alive) {
+          if (!is_delta(m.type)) {
+            // light sampling
+            V3 radiance, ldir;
+            float ltmax, lightPdf, choicePdf;
+            sample_one_light(S, rng, pos, radiance, ldir, ltmax, lightPdf, choicePdf);
+            V3 x = v3(0, 0, 0);
+            if (!is_black(radiance)) {
+              V3 fr;
+              float samplePdf;
+              eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
+              float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
+              x = weight * fr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
+              // The reference traces the shadow ray before it evaluates the BSDF
+              // (pathtracer.cu:933-940); when the term is exactly zero (light behind
+              // the surface, zero BSDF) visibility cannot change Ld, so no ray is sent.
+              want_shadow = !is_black(x);
+              so = pos; sd = ldir; stmax = ltmax;
+            }
+            // BSDF sampling for direct light
+            V3 us;
+            us.x = rng_uniform(rng); us.y = rng_uniform(rng); us.z = rng_uniform(rng);
+            V3 mo, mfr;
+            float mpdf;
+            sample_bsdf(S, m, -rd, nor, uv, dpdu, us, mo, mfr, mpdf);
+            float4 py = make_float4(0, 0, 0, 0);
+            float absdot = 0.f;
+            if (!is_black(mfr) && mpdf != 0) {
+              want_probe = true;
+              po = pos; pd = mo;
+              py = f4(mfr, mpdf);
+              absdot = fabsf(dot(mo, nor));
+#if CASTER_PROBE_CULL
+              // The probe only contributes when its closest hit is an emitter (no
+              // environment light here), so a ray that cannot reach one is not
+              // sent.  With few emitters their triangles are tested with the very
+              // test the traversal uses: if none is hit, the closest hit cannot be
+              // one; otherwise the ray starts out holding the nearest emitter hit,
+              // so that the traversal only looks for something at least as close.
+              if (!S.inf.valid) {
+                // first the padded box around all emitters: a ray that misses it cannot hit one
+                float tn;
+                bool reach = S.n_lights > 0 &&
+                             box_test(v3(S.emit_lo), v3(S.emit_hi), pos, v3(1.f / mo.x, 1.f / mo.y, 1.f / mo.z), INFINITY,
+                                      S.box_scale, tn);
+                if (!reach) {
+                  want_probe = false;
+                  py = make_float4(0, 0, 0, 0);
+                } else if (S.n_lights <= kProbeCullLights) {
+                  float pmaxD = maxcomp(vabs(mo));
+                  for (int li = 0; li < S.n_lights; ++li) {
+                    int lprim = __float_as_int(uniform_load4(S.lights + (size_t)li * kLightF4 + 4).w);
+                    const float4* rec = S.isect + (size_t)lprim * kIsectF4;
+                    float t, b1, b2;
+                    bool last;
+                    if (prim_test_rec(S, uniform_load4(rec), uniform_load4(rec + 1), uniform_load4(rec + 2), pos, mo, pmaxD,
+                                      S.epsilon, INFINITY, t, b1, b2, last) &&
+                        (t < ptmax || (t == ptmax && lprim > pseed) || pseed < 0)) {
+                      ptmax = t;
+                      pseed = lprim;
+                    }
+                  }
+                  if (pseed < 0) { want_probe = false; py = make_float4(0, 0, 0, 0); }
+                }
+              }
+#endif
+            }
+            // Li += beta * (x + y) is owed once visibility and the probe are known.
+            // Without a probe y counts as zero and is not stored; when x is zero
+            // as well the sum adds beta * 0, which only matters for a non-finite
+            // beta (the sample then turns NaN and is dropped), so a finite beta
+            // stores nothing at all.
+            bool finite_beta = fabsf(beta.x) < INFINITY && fabsf(beta.y) < INFINITY && fabsf(beta.z) < INFINITY;
+            if (want_probe || !is_black(x) || !finite_beta) {
+              P.pend_x[slot] = f4(x, absdot);
+              if (want_probe) P.pend_y[slot] = py;
+              P.beta_prev[slot] = f4(beta, 0.f);
+              flags |= kFPending | (want_probe ? kFPendingY : 0u);
+            }
+          }
+          // continuation
+          V3 u;
+          u.x = rng_uniform(rng); u.y = rng_uniform(rng); u.z = rng_uniform(rng);
+          V3 wo2, fr2;
+          float pdf2;
+          sample_bsdf(S, m, -rd, nor, uv, dpdu, u, wo2, fr2, pdf2);
+          if (is_black(fr2)) {
+            alive = false;
+          } else {
+            beta = beta * (fr2 * fabsf(dot(nor, wo2)) / pdf2);
+            specular = is_delta(m.type);
+            no = pos; nd = wo2;
+            if (bounces > 3) {
+              float illumate = fps::clamp_(1.f - luminance(beta), 0.f, 1.f);
+              if (rng_uniform(rng) < illumate) alive = false;
+              else beta = beta / (1 - illumate);
+            }
+            if (bounces + 1 >= S.maxDepth) alive = false;
+          }
+        }
+      }
+      want_next = alive;
+      flags = (flags & ~(kFBounceMask | kFSpecular)) | (uint32_t)(bounces + 1) | (specular ? kFSpecular : 0u);
+      P.beta_rng[slot] = f4(beta, rng);
+      P.li_flags[slot] = f4(Li, flags);
+    }
+    stage_push(stage.next, sbase, n_next, want_next, slot, no, -1, nd, INFINITY);
+    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, -1, sd, stmax);
+    stage_push(stage.probe, sbase, n_probe, want_probe, slot, po, pseed, pd, ptmax);
+  }
+  __syncthreads();  // the copy below reads what other lanes of this wavefront staged
+  stage_flush(stage.next, sbase, n_next, out.next);
+  stage_flush(stage.shadow, sbase, n_shadow, out.shadow);
+  stage_flush(stage.probe, sbase, n_probe, out.probe);
+}
+
+// BSDF-sampled direct light (pathtracer.cu:949-983), after the probe rays have
+// been traced: an emitter hit (or the environment on a miss) contributes
+// weight * fr * Le * |cos| / pdf into the path's pending term.
+__global__ __launch_bounds__(kWave) void k_probe_resolve(LaunchCtx L, RayQueue q) {
+  const DevScene& S = L.S;
+  const uint32_t count = *q.count;
+  for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
+    float4 o4 = q.o[idx], d4 = q.d[idx], h4 = q.hit[idx];
+    int slot = q.slot[idx];
+    V3 pos = v3(o4), out = v3(d4);
+    Hit h;
+    h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+    bool found = h.prim >= 0;
+    float4 py = L.P.pend_y[slot];
+    V3 fr = v3(py);
+    float pdf = py.w;
+    float absdot = L.P.pend_x[slot].w;
+    V3 y = v3(0, 0, 0);
+    if (found) {
+      int light = __float_as_int(S.shade[(size_t)h.prim * kShadeF4 + 6].y);
+      uint32_t type = __float_as_uint(S.shade[(size_t)h.prim * kShadeF4 + 7].x) & kPrimTypeMask;
+      if (type == 0u && light != -1) {
+        LightRec l;
+        load_light(S, light, l);
+        // a hit the ray started out with carries no barycentrics: the same test gives them again
+        {
+          float t, b1, b2;
+          bool last;
+          if (prim_test(S, h.prim, pos, out, maxcomp(vabs(out)), S.epsilon, INFINITY, t, b1, b2, last)) {
+            h.b1 = b1; h.b2 = b2;
+          }
+        }
+        const float4* sh = S.shade + (size_t)h.prim * kShadeF4;
+        V3 n = normalize(v3(sh[0]) * (1.f - h.b1 - h.b2) + v3(sh[1]) * h.b1 + v3(sh[2]) * h.b2);
+        V3 p = pos + h.t * out;
+        V3 radiance = dot(n, -out) > 0.f ? l.radiance : v3(0, 0, 0);
+        if (!is_black(radiance)) {
+          float pdfA = 1.f / l.area;
+          float choicePdf = S.light_cdf[light + 1] - S.light_cdf[light];
+          float lenSquare = dot(p - pos, p - pos);
+          float costheta = fabsf(dot(n, out));
+          float lPdf = pdfA * lenSquare / (costheta);
+          float weight = power_heuristic(pdf, lPdf * choicePdf);
+          y = weight * fr * radiance * absdot / pdf;
+        }
+      }
+    } else if (S.inf.valid) {
+      V3 radiance = inf_le(S.inf, out);
+      float choicePdf = S.light_cdf[S.n_lights + 1] - S.light_cdf[S.n_lights];
+      float lightPdf = ONE_OVER_FOUR_PI;
+      float weight = power_heuristic(pdf, lightPdf * choicePdf);
+      y = weight * fr * radiance * absdot / pdf;
+    }
+    L.P.pend_y[slot] = f4(y, 0.f);
+  }
+}
+
+// A vertex whose probe ray was never issued does not set kFPendingY, so its
+// pend_y is not read; issued ones are always overwritten by k_probe_resolve.
+
+// One vertex of Ao() (pathtracer.cu:841-868).
+__global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
+  const DevScene& S = L.S;
+  const PathState& P = L.P;
+  const uint32_t count = *cur.count;
+  uint32_t r0, r1;
+  wave_rounds(count, r0, r1);
+  const uint32_t sbase = blockIdx.x * stage.region_cap;
+  uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
+  for (uint32_t r = r0; r < r1; ++r) {
+    uint32_t idx = r * kWave + threadIdx.x;
+    bool want_shadow = false;
+    int slot = 0;
+    V3 so = v3(0, 0, 0), sd = v3(0, 0, 1);
+    if (idx < count) {
+      slot = cur.slot[idx];
+      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+      if (d4.w >= 0.f) {
+        V3 ro = v3(o4), rd = v3(d4);
+        Hit h;
+        h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+        float4 br = P.beta_rng[slot];
+        uint32_t rng = __float_as_uint(br.w);
+        uint32_t flags = 1u;
+        V3 Li = v3(0, 0, 0);
+        if (h.prim < 0) {
+          Li = v3(1, 1, 1);
+        } else {
+          Isect is;
+          load_isect(S, ro, rd, h, is);
+          V3 n = is.n;
+          float pdf = 0.f;
+          if (dot(-rd, n) < 0.f) n = -n;
+          float u1 = rng_uniform(rng);
+          float u2 = rng_uniform(rng);
+          V3 wi = cosine_hemisphere(u1, u2, pdf);
+          V3 s = is.dpdu;
+          V3 t = cross(n, s);
+          wi = to_world(wi, s, t, n);
+          float cosine = dot(wi, n);
+          float v = cosine / pdf;
+          P.pend_x[slot] = f4(v3(v, v, v), 0.f);
+          P.beta_prev[slot] = f4(v3(1, 1, 1), 0.f);
+          flags |= kFPending;
+          want_shadow = true;
+          so = is.pos; sd = wi;
+        }
+        P.beta_rng[slot] = f4(v3(br), rng);
+        P.li_flags[slot] = f4(Li, flags);
+      }
+    }
+    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, -1, sd, S.maxDist);
+  }
+  __syncthreads();
+  stage_flush(stage.shadow, sbase, n_shadow, out.shadow);
+  (void)n_next; (void)n_probe;
+}
+
+}  // namespace caster

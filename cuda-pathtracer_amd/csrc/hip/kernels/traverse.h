@@ -1,0 +1,295 @@
+// Part of the gfx950 wavefront renderer (included by ../kernels.hip, in this order: common.h, traverse.h, trace.h, shading.h, path.h, volpath.h, lighttrace.h, bdpt.h, volpath_queues.h, film.h).
+// Ray/box and ray/primitive tests, the traversal stack, one-lane closest-hit / any-hit walk.
+#pragma once
+
+namespace caster {
+
+// --------------------------------------------------------------- traversal
+// Slab test of the reference (bbox.h:75-98): tFar widened by 1+2*gamma(3),
+// rejected when behind the ray, empty, or beyond the current tmax; tmin is
+// not consulted.  Returns tNear through `tn`.
+__device__ inline bool box_test(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float scale, float& tn) {
+  float txNear = (lo.x - o.x) * inv.x;
+  float txFar = (hi.x - o.x) * inv.x;
+  float tyNear = (lo.y - o.y) * inv.y;
+  float tyFar = (hi.y - o.y) * inv.y;
+  float tzNear = (lo.z - o.z) * inv.z;
+  float tzFar = (hi.z - o.z) * inv.z;
+  // v_min_f32 / v_max_f32 drop a NaN operand exactly as fps::fmin_/fmax_ do;
+  // they may differ in the sign of a zero result, which no comparison below sees.
+  float tNear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(txNear, txFar), __builtin_fminf(tyNear, tyFar)),
+                                __builtin_fminf(tzNear, tzFar));
+  float tFar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(txNear, txFar), __builtin_fmaxf(tyNear, tyFar)),
+                               __builtin_fmaxf(tzNear, tzFar));
+  tFar *= scale;
+  tn = tNear;
+  return !(tFar <= 0.00001f) && !(tNear > tFar) && !(tNear > tmax);
+}
+
+struct Hit {
+  float t;
+  int prim;
+  float b1, b2;  // triangle barycentrics; line: s, d2
+};
+
+// Ray/primitive tests.  Each returns the candidate parameter in `t`; the
+// caller applies the closest-hit rule.  Triangle: Triangle.h:87-118 with the
+// edge vectors and coordinate maxima precomputed per primitive (the same
+// float operations, done once on the host).  Sphere: sphere.h:24-66.  Line:
+// line.h:33-72.
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, float maxD, float tmin,
+                                     float tmax, float& t, float& ob1, float& ob2, bool& last);
+__device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, float tmax,
+                                 float& t, float& ob1, float& ob2, bool& last) {
+  const float4* rec = S.isect + (size_t)i * kIsectF4;
+  return prim_test_rec(S, rec[0], rec[1], rec[2], o, d, maxD, tmin, tmax, t, ob1, ob2, last);
+}
+// The same test on a record already in registers.
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, float maxD, float tmin,
+                                     float tmax, float& t, float& ob1, float& ob2, bool& last) {
+  uint32_t bits = __float_as_uint(c.w);
+  last = (bits & kPrimLastInLeaf) != 0;
+  uint32_t type = bits & kPrimTypeMask;
+  if (type == 0u) {
+    V3 p1 = v3(a), e1 = v3(b), e2 = v3(c);
+    float maxE = a.w, maxP1 = b.w;
+    V3 s1 = cross(d, e2);
+    float divisor = dot(s1, e1);
+    if (fabsf(divisor) < 1e-8f) return false;
+    float inv = 1.0f / divisor;
+    V3 s = o - p1;
+    float b1 = dot(s, s1) * inv;
+    if (b1 < 0.0f || b1 > 1.0f) return false;
+    V3 s2 = cross(s, e1);
+    float b2 = dot(d, s2) * inv;
+    if (b2 < 0.0f || b1 + b2 > 1.0f) return false;
+    float deltaE = S.g1 * maxE;
+    float deltaS1 = 2 * (S.g2 * maxD * maxE + deltaE * maxD);
+    float deltaS = S.g1 * maxP1;
+    float maxS = maxcomp(vabs(s));
+    float maxS1 = maxcomp(vabs(s1));
+    float deltaS2 = 2 * (S.g2 * maxS * maxS1 + deltaS * maxS1 + deltaS1 * maxS);
+    float maxS2 = maxcomp(vabs(s2));
+    float deltaT = 2 * (S.g2 * maxE * maxS2 + deltaS2 * maxE + deltaE * maxS2) * fabsf(inv);
+    float tt = dot(e2, s2) * inv;
+    if (tt < tmin + deltaT || tt > tmax) return false;
+    t = tt; ob1 = b1; ob2 = b2;
+    return true;
+  }
+  if (type == 2u) {
+    V3 op = o - v3(a);
+    float radius = a.w;
+    float B = dot(op, d);
+    float C = dot(op, op) - radius * radius;
+    float delta = B * B - C;
+    if (delta < 0.f) return false;
+    float sq = sqrtf(delta);
+    float t1 = -B - sq;
+    float t2 = -B + sq;
+    if (t1 < 0.f && t2 < 0.f) return false;
+    if (t1 < 0.f || t2 < 0.f) {
+      float tt1 = t1, tt2 = t2;
+      t1 = tt1 < 0.f ? tt2 : tt1;
+      t2 = tt1 < 0.f ? tt1 : tt2;
+    } else if (t1 > t2) {
+      float tmp = t2; t2 = t1; t1 = tmp;
+    }
+    if (t1 > tmax) return false;
+    float th;
+    if (t1 > tmin) th = t1;
+    else if (t2 > 0.f) th = t2;
+    else return false;
+    if (th > tmax) return false;
+    t = th; ob1 = 0.f; ob2 = 0.f;
+    return true;
+  }
+  {
+    V3 p0 = v3(a), p1 = v3(b);
+    V3 u = d;
+    V3 v = p1 - p0;
+    V3 w = o - p0;
+    float aa = dot(u, u), bb = dot(u, v), cc = dot(v, v), dd = dot(u, w), ee = dot(v, w);
+    float det = aa * cc - bb * bb;
+    if (det == 0) return false;
+    float tt = (bb * ee - cc * dd) / det;
+    float s = (aa * ee - bb * dd) / det;
+    if (tt < tmin || tt > tmax) return false;
+    s = fps::clamp_(s, 0.f, 1.f);
+    V3 pr = o + d * tt;
+    V3 pl = p0 + (p1 - p0) * s;
+    V3 prl = pr - pl;
+    float d2 = dot(prl, prl);
+    float r = a.w * (1 - s) + b.w * s;
+    if (d2 > r * r) return false;
+    t = tt; ob1 = s; ob2 = d2;
+    return true;
+  }
+}
+
+// Traversal stack: (child reference, entry distance) pairs.  The first
+// kLdsDepth entries of a lane live in LDS, lane-strided so that one wavefront
+// push or pop is a single conflict-free 8-byte ds access; deeper entries go to
+// a per-lane column in HBM (lane-strided too, so a wavefront's spill is one
+// coalesced store).
+struct WalkAux {
+  uint32_t* work;         // kWorkShards counters: next unclaimed ray of each part of the queue being traced
+  uint2* spill;           // kSpillDepth x spill_stride entries
+  uint32_t spill_stride;  // lanes in the launch grid
+};
+struct Stack {
+  uint2 (*lds)[kWave];
+  uint2* spill;  // this lane's column
+  uint32_t stride;
+  int sp;
+};
+#ifndef CASTER_STACK_SPLIT
+#define CASTER_STACK_SPLIT 1
+#endif
+#if CASTER_STACK_SPLIT
+// The LDS entries are accessed as one volatile 64-bit word: that keeps each push
+// and pop a single ds_write_b64 / ds_read_b64, where the optimiser would
+// otherwise merge the LDS and the spill branch into 32-bit flat accesses.
+typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64_t;
+__device__ inline void lds_put(Stack& s, int sp, uint32_t lane, uint2 e) {
+  *(lds_u64_t*)&s.lds[sp][lane] = ((unsigned long long)e.y << 32) | e.x;
+}
+__device__ inline uint2 lds_get(Stack& s, int sp, uint32_t lane) {
+  unsigned long long v = *(lds_u64_t*)&s.lds[sp][lane];
+  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+#else
+__device__ inline void lds_put(Stack& s, int sp, uint32_t lane, uint2 e) { s.lds[sp][lane] = e; }
+__device__ inline uint2 lds_get(Stack& s, int sp, uint32_t lane) { return s.lds[sp][lane]; }
+#endif
+__device__ inline bool stack_push(Stack& s, uint32_t lane, int ref, float tn) {
+  uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
+  if (s.sp < kLdsDepth) lds_put(s, s.sp, lane, e);
+  else if (s.sp < kLdsDepth + kSpillDepth) s.spill[(size_t)(s.sp - kLdsDepth) * s.stride] = e;
+  else return false;
+  ++s.sp;
+  return true;
+}
+// Next deferred child that can still hold a closer hit: an entry whose entry
+// distance exceeds the current tmax is dropped, which is the test the
+// reference makes when it reaches that node (pathtracer.cu:231-232,
+// bbox.h:95).  kRefEmpty when nothing is left.
+__device__ inline int stack_next(Stack& s, uint32_t lane, float tmax) {
+  while (s.sp > 0) {
+    --s.sp;
+    uint2 e;
+    if (s.sp < kLdsDepth) e = lds_get(s, s.sp, lane);
+    else e = s.spill[(size_t)(s.sp - kLdsDepth) * s.stride];
+    if (!(__uint_as_float(e.y) > tmax)) return (int)e.x;
+  }
+  return kRefEmpty;
+}
+
+// One 4-wide node: four slab tests, the children that pass sorted nearest
+// first; the nearest is returned, the others are deferred.
+// Nodes below `n_top` are read from the workgroup's LDS copy `top` (7 x 16 B
+// per node) instead of through the vector memory pipeline.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4f_t lds_v4f_t;
+__device__ inline float4 lds_f4(const float4* p) {
+  v4f_t v = *(const lds_v4f_t*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+constexpr int kTopF4 = 7;
+template <bool SORT = true>
+__device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float tmax, Stack& st, uint32_t lane,
+                                unsigned long long* overflow, const float4* top = nullptr, int n_top = 0) {
+  float4 lx, ly, lz, hx, hy, hz, rf;
+  if (cur < n_top) {
+    const float4* n = top + cur * kTopF4;
+    lx = lds_f4(n); ly = lds_f4(n + 1); lz = lds_f4(n + 2); hx = lds_f4(n + 3); hy = lds_f4(n + 4); hz = lds_f4(n + 5);
+    rf = lds_f4(n + 6);
+  } else {
+    const float4* n = S.nodes + (size_t)cur * kNodeF4;
+    lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; rf = n[6];
+  }
+  int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+  float k0, k1, k2, k3;
+  bool h0 = box_test(v3(lx.x, ly.x, lz.x), v3(hx.x, hy.x, hz.x), o, inv, tmax, S.box_scale, k0) && r0 != kRefEmpty;
+  bool h1 = box_test(v3(lx.y, ly.y, lz.y), v3(hx.y, hy.y, hz.y), o, inv, tmax, S.box_scale, k1) && r1 != kRefEmpty;
+  bool h2 = box_test(v3(lx.z, ly.z, lz.z), v3(hx.z, hy.z, hz.z), o, inv, tmax, S.box_scale, k2) && r2 != kRefEmpty;
+  bool h3 = box_test(v3(lx.w, ly.w, lz.w), v3(hx.w, hy.w, hz.w), o, inv, tmax, S.box_scale, k3) && r3 != kRefEmpty;
+  int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+  if (nh == 0) return stack_next(st, lane, tmax);
+  k0 = h0 ? k0 : INFINITY; k1 = h1 ? k1 : INFINITY; k2 = h2 ? k2 : INFINITY; k3 = h3 ? k3 : INFINITY;
+#define CASTER_CSWAP(ka, ra, kb, rb)        \
+  if (kb < ka) {                             \
+    float tk_ = ka; ka = kb; kb = tk_;       \
+    int tr_ = ra; ra = rb; rb = tr_;         \
+  }
+  if (SORT) {
+    CASTER_CSWAP(k0, r0, k1, r1)
+    CASTER_CSWAP(k2, r2, k3, r3)
+    CASTER_CSWAP(k0, r0, k2, r2)
+    CASTER_CSWAP(k1, r1, k3, r3)
+    CASTER_CSWAP(k1, r1, k2, r2)
+  } else {
+    // any-hit rays: children that are hit first, in no particular order (the network
+    // sorts the hit flags; an exchange moves a miss behind a hit)
+#define CASTER_CMOVE(ha, ka, ra, hb, kb, rb)              \
+    if (!ha && hb) {                                       \
+      float tk_ = ka; ka = kb; kb = tk_;                   \
+      int tr_ = ra; ra = rb; rb = tr_;                     \
+      ha = true; hb = false;                               \
+    }
+    CASTER_CMOVE(h0, k0, r0, h1, k1, r1)
+    CASTER_CMOVE(h2, k2, r2, h3, k3, r3)
+    CASTER_CMOVE(h0, k0, r0, h2, k2, r2)
+    CASTER_CMOVE(h1, k1, r1, h3, k3, r3)
+    CASTER_CMOVE(h1, k1, r1, h2, k2, r2)
+#undef CASTER_CMOVE
+  }
+#undef CASTER_CSWAP
+  bool ok = true;
+  if (nh > 3) ok &= stack_push(st, lane, r3, k3);
+  if (nh > 2) ok &= stack_push(st, lane, r2, k2);
+  if (nh > 1) ok &= stack_push(st, lane, r1, k1);
+  if (!ok) atomicAdd(overflow, 1ull);
+  return r0;
+}
+
+// Tests the primitives of the leaf starting at `i`.  Among hits at equal
+// distance the higher primitive index wins, as in the reference's in-order
+// scan with its `t <= tmax` acceptance.  ANY: returns at the first hit.
+template <bool ANY>
+__device__ inline bool leaf_step(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, Hit& hit) {
+  bool last;
+  do {
+    float t, b1, b2;
+    if (prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last)) {
+      if (ANY) return true;
+      if (t < hit.t || i > hit.prim) { hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2; }
+    }
+    ++i;
+  } while (!last);
+  return false;
+}
+
+// Closest-hit (ANY=false) or any-hit (ANY=true) walk of one ray by one lane.
+template <bool ANY>
+__device__ inline bool traverse(const DevScene& S, V3 o, V3 d, float tmin, float tmax, Hit& hit, Stack& st,
+                                unsigned long long* overflow) {
+  const uint32_t lane = threadIdx.x & 63u;
+  V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  float maxD = maxcomp(vabs(d));
+  hit.prim = -1;
+  hit.t = tmax;
+  hit.b1 = hit.b2 = 0.f;
+  st.sp = 0;
+  int cur = S.n_nodes ? 0 : kRefEmpty;
+  while (cur != kRefEmpty) {
+    if (cur >= 0) {
+      cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
+    } else {
+      if (leaf_step<ANY>(S, ~cur, o, d, maxD, tmin, hit)) return true;
+      cur = stack_next(st, lane, hit.t);
+    }
+  }
+  return hit.prim >= 0;
+}
+
+}  // namespace caster
