@@ -93,11 +93,8 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
     int pseed = -1;
     if (active) {
       slot = cur.slot[idx];
-      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
-      active = d4.w >= 0.f || __float_as_int(h4.y) >= 0;
-      if (!active) {
-        // slot outside the image: nothing to do, it never contributes
-      }
+      float4 d4 = cur.d[idx], h4 = cur.hit[idx];
+      active = d4.w >= 0.f || __float_as_int(h4.y) >= 0;  // else a slot outside the image: it never contributes
     }
     if (active) {
       float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
