@@ -202,3 +202,24 @@ def test_save_image_matches_film(caster, tmp_path):
     raw = open(tmp_path / "f.pfm", "rb").read()
     head = ("PF\n%d %d\n-1.0\n" % (sc.width, sc.height)).encode()
     np.testing.assert_array_equal(np.frombuffer(raw[len(head):], np.float32).reshape(mean.shape), mean)
+
+
+def test_render_tool_writes_the_film(caster, tmp_path):
+    """tools/render.py (the headless front end) on one GPU: its .pfm holds the linear mean the
+    library returns for the same scene and sample count."""
+    import subprocess
+    import sys
+    key = sorted(VEC["scenes"])[0]
+    scene = os.path.join(GOLD, "scenes", key, "scene.json")
+    out = str(tmp_path / "image.pfm")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "render.py"), scene, "--spp", "5", "--iters-in-flight", "2",
+                        "--out", out], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    head = open(out, "rb").read().split(b"\n", 3)
+    w, h = map(int, head[1].split())
+    image = np.frombuffer(head[3], "<f4").reshape(h, w, 3)
+    sc = caster.Scene(scene)
+    r = caster.Renderer(sc, 0, 2)
+    r.render(1, 5, True)
+    np.testing.assert_array_equal(image, r.read_film(0))
+    r.close()
