@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE -- not part of the product.
 //
 // CPU oracle: a plain, scalar restatement of the reference's AO / path /
-// volumetric-path / light-tracing integrators and every device function they call.  One
+// volumetric-path / light-tracing / bidirectional integrators and every device function they call.  One
 // function per reference function, each citing the lines it follows
 // (paths relative to CUDA-PathTracer/tracer/).  The reference does not compile
 // and ships no tests, scenes or golden vectors, so parity against it is
