@@ -67,3 +67,45 @@ def test_full_size_config(caster, tmp_path, key):
     assert band_cpu.mean() > 1e-3
     assert rel_rmse(band_gpu, band_cpu) <= 1e-3
     np.testing.assert_array_equal(band_gpu, band_cpu)
+
+
+@pytest.mark.parametrize("integrator", ["lt", "bdpt"])
+def test_splatting_integrators_at_full_size(caster, tmp_path, integrator):
+    """Light tracing and BDPT on the staircase scene at 1920x1080: the oracle cannot render the frame,
+    so (1) the walks of a band of rows are the oracle's, ray for ray (counts of sub-path rays and
+    transmittance segments), and its film equals the oracle's to the tolerance of the splatting
+    integrators; (2) the films of two bands of rows add up to the film of the whole frame."""
+    import json
+    path = gen_scenes.generate(str(tmp_path / "s"), "stairs_pt", 1.0, 1920, 1080, 8)
+    doc = json.load(open(path))
+    doc["integrator"] = integrator
+    json.dump(doc, open(path, "w"))
+    o = ol.Oracle(path)
+    sc = caster.Scene(path)
+    assert caster.INTEGRATOR_NAMES[sc.integrator] == integrator
+    rows = (536, 540)
+    counts = ol.Counts()
+    cpu = o.render(1, 1, 8, counts=counts, rows=rows)
+    r = caster.Renderer(sc, 0, 1)
+    r.set_rows(*rows)
+    r.render(1, 1, True)
+    band = r.read_film(2)
+    st = r.stats()
+    c = counts.as_dict()
+    assert st["stack_overflow"] == 0 and st["rays"][3] == c["rays"][3]
+    if integrator == "bdpt":
+        assert st["rays"][0] == c["rays"][0]
+    d = (band - cpu) / (np.abs(cpu) + 1e-2)
+    assert cpu.sum() > 0 and float(np.sqrt(np.mean(d * d))) <= 1e-5
+    # two halves of the frame against the whole
+    total = np.zeros_like(band)
+    for y0, y1 in ((0, 536), (536, 1080)):
+        r.set_rows(y0, y1)
+        r.render(1, 1, True)
+        total += r.read_film(2)
+    r.set_rows(0, 1080)
+    r.render(1, 1, True)
+    whole = r.read_film(2)
+    r.close()
+    d = (total - whole) / (np.abs(whole) + 1e-2)
+    assert whole.mean() > 1e-4 and float(np.sqrt(np.mean(d * d))) <= 1e-5
