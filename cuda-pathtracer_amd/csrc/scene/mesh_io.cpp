@@ -495,48 +495,20 @@ bool load_jpeg(const std::string& data, Image8& im, std::string& err) {
 
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
 
-// Non-interlaced 8-bit grey / RGB / RGBA PNG.
-bool load_png(const std::string& data, Image8& im, std::string& err) {
-  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-  if (data.size() < 8 || memcmp(data.data(), sig, 8) != 0) { err = "not a PNG"; return false; }
-  const uint8_t* d = (const uint8_t*)data.data();
-  size_t p = 8;
-  std::vector<uint8_t> z;
-  int depth = 0, ctype = 0, interlace = 0;
-  while (p + 8 <= data.size()) {
-    uint32_t len = be32(d + p);
-    std::string ty(data, p + 4, 4);
-    if (p + 12 + len > data.size()) break;
-    if (ty == "IHDR") {
-      im.w = (int)be32(d + p + 8); im.h = (int)be32(d + p + 12);
-      depth = d[p + 16]; ctype = d[p + 17]; interlace = d[p + 20];
-    } else if (ty == "IDAT") {
-      z.insert(z.end(), d + p + 8, d + p + 8 + len);
-    } else if (ty == "IEND") break;
-    p += 12 + len;
-  }
-  if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 6)) {
-    err = "PNG must be 8-bit, non-interlaced, grey/RGB/RGBA"; return false;
-  }
-  im.comp = ctype == 0 ? 1 : (ctype == 2 ? 3 : 4);
-  size_t stride = (size_t)im.w * im.comp;
-  std::vector<uint8_t> raw((stride + 1) * im.h);
-  uLongf rawlen = raw.size();
-  if (uncompress(raw.data(), &rawlen, z.data(), z.size()) != Z_OK || rawlen != raw.size()) {
-    err = "PNG inflate failed"; return false;
-  }
-  im.px.resize(stride * im.h);
-  int bpp = im.comp;
-  for (int y = 0; y < im.h; ++y) {
-    const uint8_t* in = raw.data() + (stride + 1) * y;
-    uint8_t* out = im.px.data() + stride * y;
-    const uint8_t* up = y ? out - stride : nullptr;
-    int ft = in[0];
+// Undo the per-row PNG filters of one (sub-)image in place: `rows` rows of
+// 1 filter byte + `stride` data bytes each.
+bool png_unfilter(uint8_t* raw, size_t stride, int rows, int bpp) {
+  for (int y = 0; y < rows; ++y) {
+    uint8_t* row = raw + (stride + 1) * y;
+    const uint8_t* up = y ? row - stride : nullptr;  // previous row's data starts one byte later
+    const int ft = row[0];
+    if (ft > 4) return false;
+    uint8_t* out = row + 1;
     for (size_t x = 0; x < stride; ++x) {
       int a = x >= (size_t)bpp ? out[x - bpp] : 0;
       int b = up ? up[x] : 0;
       int c = (up && x >= (size_t)bpp) ? up[x - bpp] : 0;
-      int v = in[1 + x];
+      int v = out[x];
       switch (ft) {
         case 1: v += a; break;
         case 2: v += b; break;
@@ -549,6 +521,118 @@ bool load_png(const std::string& data, Image8& im, std::string& err) {
         default: break;
       }
       out[x] = (uint8_t)v;
+    }
+  }
+  return true;
+}
+
+// PNG: grey (1-16 bit), RGB, RGBA (8/16 bit) and palette (1-8 bit) images,
+// plain or Adam7-interlaced, with the 8-bit results stb_image hands the
+// reference (imageio.cpp:15): grey samples below 8 bits are spread over
+// 0..255, 16-bit samples keep their high byte, a palette becomes RGB (RGBA
+// with a tRNS chunk), an RGB colour key becomes an alpha channel.  Grey+alpha
+// is refused: the reference has no branch for two components.
+bool load_png(const std::string& data, Image8& im, std::string& err) {
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (data.size() < 8 || memcmp(data.data(), sig, 8) != 0) { err = "not a PNG"; return false; }
+  const uint8_t* d = (const uint8_t*)data.data();
+  size_t p = 8;
+  std::vector<uint8_t> z;
+  int depth = 0, ctype = 0, interlace = 0, n_pal = 0, n_trns = 0;
+  uint8_t pal[256 * 4];
+  uint8_t trns[256];
+  for (int i = 0; i < 256; ++i) pal[4 * i + 3] = 255;
+  bool have_trns = false;
+  while (p + 8 <= data.size()) {
+    uint32_t len = be32(d + p);
+    std::string ty(data, p + 4, 4);
+    if (p + 12 + (size_t)len > data.size()) break;
+    const uint8_t* body = d + p + 8;
+    if (ty == "IHDR" && len >= 13) {
+      im.w = (int)be32(body); im.h = (int)be32(body + 4);
+      depth = body[8]; ctype = body[9]; interlace = body[12];
+    } else if (ty == "PLTE") {
+      n_pal = (int)std::min<uint32_t>(len / 3, 256);
+      for (int i = 0; i < n_pal; ++i) { pal[4 * i] = body[3 * i]; pal[4 * i + 1] = body[3 * i + 1]; pal[4 * i + 2] = body[3 * i + 2]; }
+    } else if (ty == "tRNS") {
+      have_trns = true;
+      n_trns = (int)std::min<uint32_t>(len, 256);
+      memcpy(trns, body, n_trns);
+    } else if (ty == "IDAT") {
+      z.insert(z.end(), body, body + len);
+    } else if (ty == "IEND") break;
+    p += 12 + len;
+  }
+  int chan = 0;
+  bool ok_depth = false;
+  switch (ctype) {
+    case 0: chan = 1; ok_depth = depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16; break;
+    case 2: chan = 3; ok_depth = depth == 8 || depth == 16; break;
+    case 3: chan = 1; ok_depth = depth == 1 || depth == 2 || depth == 4 || depth == 8; break;
+    case 6: chan = 4; ok_depth = depth == 8 || depth == 16; break;
+    default: break;
+  }
+  if (im.w <= 0 || im.h <= 0 || (size_t)im.w * im.h > (1u << 28)) { err = "bad PNG header"; return false; }
+  if (ctype == 4 || (ctype == 0 && have_trns)) { err = "grey+alpha PNG (the reference reads two-component images as garbage)"; return false; }
+  if (!ok_depth || interlace > 1) { err = "unsupported PNG colour type / bit depth"; return false; }
+  if (ctype == 3 && n_pal == 0) { err = "palette PNG without PLTE"; return false; }
+  if (ctype == 2 && have_trns && n_trns < 6) { err = "short tRNS chunk"; return false; }
+
+  // Sub-images: the whole picture, or the seven Adam7 passes.
+  static const int x0[7] = {0, 4, 0, 2, 0, 1, 0}, y0[7] = {0, 0, 4, 0, 2, 0, 1};
+  static const int dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+  struct Pass { int w, h, x0, y0, dx, dy; size_t stride, off; };
+  std::vector<Pass> passes;
+  size_t total = 0;
+  const int bits = chan * depth;
+  for (int i = 0; i < (interlace ? 7 : 1); ++i) {
+    Pass q;
+    if (interlace) {
+      q.x0 = x0[i]; q.y0 = y0[i]; q.dx = dx[i]; q.dy = dy[i];
+      q.w = (im.w - q.x0 + q.dx - 1) / q.dx; q.h = (im.h - q.y0 + q.dy - 1) / q.dy;
+    } else { q.x0 = q.y0 = 0; q.dx = q.dy = 1; q.w = im.w; q.h = im.h; }
+    if (q.w <= 0 || q.h <= 0) continue;
+    q.stride = ((size_t)q.w * bits + 7) / 8;
+    q.off = total;
+    total += (q.stride + 1) * q.h;
+    passes.push_back(q);
+  }
+  std::vector<uint8_t> raw(total);
+  uLongf rawlen = raw.size();
+  if (uncompress(raw.data(), &rawlen, z.data(), z.size()) != Z_OK || rawlen != raw.size()) {
+    err = "PNG inflate failed"; return false;
+  }
+  const bool key = ctype == 2 && have_trns;
+  im.comp = ctype == 3 ? (have_trns ? 4 : 3) : (key ? 4 : chan);
+  im.px.assign((size_t)im.w * im.h * im.comp, 0);
+  const int bpp = std::max(1, bits / 8);
+  const int grey_scale = depth == 1 ? 0xff : depth == 2 ? 0x55 : depth == 4 ? 0x11 : 1;
+  for (int i = 0; i < n_trns && ctype == 3; ++i) pal[4 * i + 3] = trns[i];
+  for (const Pass& q : passes) {
+    uint8_t* sub = raw.data() + q.off;
+    if (!png_unfilter(sub, q.stride, q.h, bpp)) { err = "bad PNG filter"; return false; }
+    for (int y = 0; y < q.h; ++y) {
+      const uint8_t* row = sub + (q.stride + 1) * y + 1;
+      for (int x = 0; x < q.w; ++x) {
+        uint8_t* out = im.px.data() + ((size_t)(q.y0 + y * q.dy) * im.w + (q.x0 + x * q.dx)) * im.comp;
+        if (depth < 8) {
+          const int per = 8 / depth;
+          const int v = (row[x / per] >> (8 - depth * (x % per + 1))) & ((1 << depth) - 1);
+          if (ctype == 3) memcpy(out, pal + 4 * v, im.comp);
+          else out[0] = (uint8_t)(v * grey_scale);
+        } else if (ctype == 3) {
+          memcpy(out, pal + 4 * row[x], im.comp);
+        } else {
+          const int step = depth / 8;
+          const uint8_t* s = row + (size_t)x * chan * step;
+          for (int c = 0; c < chan; ++c) out[c] = s[c * step];  // 16 bit: the high byte
+          if (key) {  // tRNS holds the key as three big-endian 16-bit samples
+            const bool hit = step == 2 ? memcmp(s, trns, 6) == 0
+                                       : (s[0] == trns[1] && s[1] == trns[3] && s[2] == trns[5]);
+            out[3] = hit ? 0 : 255;
+          }
+        }
+      }
     }
   }
   return true;

@@ -376,3 +376,137 @@ def test_progressive_jpeg_is_refused(caster, tmp_path):
            "scene": [{"mesh": "q.obj", "material": "m"}]}
     with pytest.raises(caster.CasterError, match="progressive"):
         caster.Scene(write_scene(tmp_path, doc, [("q.obj", QUAD)]))
+
+
+def _png_bytes(samples, ctype, depth, interlace=False, palette=None, trns=None):
+    """A PNG file of `samples` (h, w, channels; integers below 2**depth), written here so that every
+    colour type, bit depth, row filter and the Adam7 order can be asked for."""
+    import struct
+    import zlib
+    h, w, ch = samples.shape
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+
+    def pack_rows(sub, first_filter):
+        out = bytearray()
+        bpp = max(1, ch * depth // 8)
+        prev = None
+        for y in range(sub.shape[0]):
+            row = sub[y].reshape(-1)
+            if depth == 16:
+                line = row.astype(">u2").tobytes()
+            elif depth == 8:
+                line = row.astype(np.uint8).tobytes()
+            else:
+                bits = np.zeros(((len(row) * depth + 7) // 8) * 8, np.uint8)
+                for b in range(depth):
+                    bits[np.arange(len(row)) * depth + b] = (row >> (depth - 1 - b)) & 1
+                line = np.packbits(bits).tobytes()
+            cur = np.frombuffer(line, np.uint8).astype(np.int32)
+            up = prev if prev is not None else np.zeros_like(cur)
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            upleft = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            ft = (first_filter + y) % 5
+            if ft == 0:
+                enc = cur
+            elif ft == 1:
+                enc = cur - left
+            elif ft == 2:
+                enc = cur - up
+            elif ft == 3:
+                enc = cur - (left + up) // 2
+            else:
+                pa, pb, pc = abs(up - upleft), abs(left - upleft), abs(left + up - 2 * upleft)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, upleft))
+                enc = cur - pred
+            out += bytes([ft]) + (enc & 255).astype(np.uint8).tobytes()
+            prev = cur
+        return bytes(out)
+
+    if interlace:
+        x0, y0, dx, dy = (0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)
+        raw = b"".join(pack_rows(samples[y0[i]::dy[i], x0[i]::dx[i]], i) for i in range(7)
+                       if samples[y0[i]::dy[i], x0[i]::dx[i]].size)
+    else:
+        raw = pack_rows(samples, 0)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, int(interlace)))
+    if palette is not None:
+        out += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", trns)
+    half = len(raw) // 2                                             # two IDAT chunks: the stream is their concatenation
+    z = zlib.compress(raw, 6)
+    return out + chunk(b"IDAT", z[:half // 3 + 1]) + chunk(b"IDAT", z[half // 3 + 1:]) + chunk(b"IEND", b"")
+
+
+PNG_CASES = {
+    "grey1": (0, 1, False), "grey2": (0, 2, True), "grey4": (0, 4, False), "grey8": (0, 8, True), "grey16": (0, 16, False),
+    "rgb8": (2, 8, True), "rgb16": (2, 16, False), "rgb8key": (2, 8, False), "rgb16key": (2, 16, True),
+    "pal1": (3, 1, False), "pal2": (3, 2, False), "pal4": (3, 4, True), "pal8": (3, 8, False), "pal8trns": (3, 8, True),
+    "rgba8": (6, 8, True), "rgba16": (6, 16, False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(PNG_CASES))
+def test_png_variants(tmp_path, case):
+    """Every PNG layout stb_image decodes for the reference (imageio.cpp:15) gives the texels of the
+    plain 8-bit file of the same picture: grey below 8 bits spread over 0..255, the high byte of 16-bit
+    samples, palette entries (with tRNS alphas), an RGB colour key as alpha, interlaced or not."""
+    from PIL import Image
+    import struct
+    import oracle_lib as ol
+    ctype, depth, interlace = PNG_CASES[case]
+    rng = np.random.RandomState(len(case) * 7 + depth)
+    w, h = 13, 11                                                    # narrower than an Adam7 cell in places
+    ch = {0: 1, 2: 3, 3: 1, 6: 4}[ctype]
+    samples = rng.randint(0, 2 ** depth, size=(h, w, ch)).astype(np.int64)
+    palette = trns = None
+    if ctype == 3:
+        palette = rng.randint(0, 256, size=(2 ** depth, 3))
+        if "trns" in case:
+            trns = bytes(rng.randint(0, 256, size=100).astype(np.uint8))   # shorter than the palette: the rest is opaque
+            alpha = np.full(2 ** depth, 255)
+            alpha[:100] = np.frombuffer(trns, np.uint8)
+            want = np.concatenate([palette[samples[:, :, 0]], alpha[samples[:, :, 0]][:, :, None]], axis=2)
+        else:
+            want = palette[samples[:, :, 0]]
+    elif ctype == 0:
+        want = np.repeat(samples * {1: 255, 2: 85, 4: 17, 8: 1}[depth] if depth < 16 else samples >> 8, 3, axis=2)
+    else:
+        want = samples >> (depth - 8)
+        if "key" in case:
+            keyv = samples[3, 5].copy()
+            samples[7, 2] = keyv                                    # two texels match the key
+            want = samples >> (depth - 8)
+            trns = struct.pack(">HHH", *[int(v) for v in keyv])
+            hit = np.all(samples == keyv, axis=2)
+            assert hit.sum() >= 2
+            want = np.concatenate([want, np.where(hit, 0, 255)[:, :, None]], axis=2)
+    tex = {}
+    for name, blob in (("got", _png_bytes(samples, ctype, depth, interlace, palette, trns)), ("want", None)):
+        d = tmp_path / name
+        d.mkdir()
+        if blob is None:
+            Image.fromarray(want.astype(np.uint8), "RGBA" if want.shape[2] == 4 else "RGB").save(str(d / "t.png"))
+        else:
+            (d / "t.png").write_bytes(blob)
+            if depth <= 8 or ctype == 0:                             # Pillow reads our file too (not 16-bit colour)
+                assert Image.open(str(d / "t.png")).size == (w, h)
+        doc = {"camera": {}, "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "t.png"}],
+               "scene": [{"mesh": "q.obj", "material": "m"}]}
+        tex[name] = ol.Oracle(write_scene(d, doc, [("q.obj", QUAD)])).texture(0)
+    assert tex["got"].shape == (h, w, 4)
+    assert np.array_equal(tex["got"], tex["want"])
+    assert tex["got"][:, :, :3].std() > 5
+
+
+def test_png_refusals(caster, tmp_path):
+    doc = {"camera": {}, "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "t.png"}],
+           "scene": [{"mesh": "q.obj", "material": "m"}]}
+    ga = np.zeros((4, 4, 2), np.int64)
+    for blob, needle in ((_png_bytes(ga, 4, 8), "grey\\+alpha"), (_png_bytes(ga[:, :, :1], 3, 8), "without PLTE"),
+                         (_png_bytes(ga[:, :, :1], 0, 8)[:60], "inflate")):
+        (tmp_path / "t.png").write_bytes(blob)
+        with pytest.raises(caster.CasterError, match=needle):
+            caster.Scene(write_scene(tmp_path, doc, [("q.obj", QUAD)]))
