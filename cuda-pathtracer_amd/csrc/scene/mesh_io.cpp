@@ -266,11 +266,12 @@ bool load_ppm(const std::string& data, Image8& im) {
   return true;
 }
 
-// Baseline (and extended sequential) Huffman JPEG, 8 bits, one or three components, sampling
-// factors 1 or 2, restart intervals: what the reference gets from stb_image for such a file
-// (imageio.cpp:12-17) up to the last bit of the inverse DCT and the colour conversion, which
-// differ between decoders (stb's are fixed-point; these are floating-point): parity unpinned to
-// +-1 level.  Progressive, arithmetic-coded, 12-bit and CMYK files are refused.
+// Huffman-coded JPEG, baseline, extended sequential or progressive, 8 bits, one or three
+// components, sampling factors 1 or 2, interleaved or one scan per component, restart intervals:
+// what the reference gets from stb_image for such a file (imageio.cpp:12-17) up to the last bit
+// of the inverse DCT and the colour conversion, which differ between decoders (stb's are
+// fixed-point; these are floating-point): parity unpinned to +-1 level.  Arithmetic-coded,
+// lossless, 12-bit and CMYK files are refused.
 struct JpegHuff {
   uint8_t bits[17] = {0};
   uint8_t vals[256] = {0};
@@ -329,19 +330,18 @@ bool load_jpeg(const std::string& data, Image8& im, std::string& err) {
   if (n < 4 || p[0] != 0xff || p[1] != 0xd8) return false;
   uint16_t qt[4][64] = {{0}};
   JpegHuff hdc[4], hac[4];
-  struct Comp { int id, h, v, tq, td, ta, pred; int pw, ph; std::vector<uint8_t> plane; };
+  // coef: the quantised coefficients of every block of the component, in zigzag order, filled
+  // scan by scan (one scan for a baseline file, many for a progressive one)
+  struct Comp { int id, h, v, tq, td, ta, pred; int pw, ph, bw, bh; std::vector<int> coef; std::vector<uint8_t> plane; };
   std::vector<Comp> comps;
-  int W = 0, H = 0, restart = 0;
+  int W = 0, H = 0, restart = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
   size_t at = 2;
-  bool have_frame = false;
-  float cosv[8][8];
-  for (int x = 0; x < 8; ++x)
-    for (int u = 0; u < 8; ++u) cosv[x][u] = (u == 0 ? 0.70710678118654752f : 1.f) * cosf((2 * x + 1) * u * 3.14159265358979323846f / 16.f);
+  bool have_frame = false, progressive = false, have_scan = false;
   while (at + 4 <= n) {
     if (p[at] != 0xff) { ++at; continue; }
     uint8_t m = p[at + 1];
     at += 2;
-    if (m == 0xd8 || m == 0x01 || (m >= 0xd0 && m <= 0xd7) || m == 0xff) { if (m == 0xff) --at; continue; }
+    if (m == 0xd8 || m <= 0x01 || (m >= 0xd0 && m <= 0xd7) || m == 0xff) { if (m == 0xff) --at; continue; }
     if (m == 0xd9) break;
     if (at + 2 > n) break;
     size_t len = ((size_t)p[at] << 8) | p[at + 1];
@@ -369,8 +369,10 @@ bool load_jpeg(const std::string& data, Image8& im, std::string& err) {
         q += total;
         h.build();
       }
-    } else if (m == 0xc0 || m == 0xc1) {
+    } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {
+      if (have_frame) { err = "JPEG with two frame headers"; return false; }
       if (qe - q < 6 || q[0] != 8) { err = "only 8-bit JPEG is supported"; return false; }
+      progressive = m == 0xc2;
       H = (q[1] << 8) | q[2]; W = (q[3] << 8) | q[4];
       int nc = q[5];
       if ((nc != 1 && nc != 3) || qe - q < 6 + 3 * nc || W <= 0 || H <= 0) { err = "JPEG with 1 or 3 components expected"; return false; }
@@ -379,118 +381,220 @@ bool load_jpeg(const std::string& data, Image8& im, std::string& err) {
         comps[c].id = q[6 + 3 * c]; comps[c].h = q[7 + 3 * c] >> 4; comps[c].v = q[7 + 3 * c] & 15; comps[c].tq = q[8 + 3 * c] & 3;
         if (comps[c].h < 1 || comps[c].h > 2 || comps[c].v < 1 || comps[c].v > 2) { err = "JPEG sampling factors above 2 are not supported"; return false; }
       }
+      if (nc == 1) comps[0].h = comps[0].v = 1;
+      for (auto& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+      mcux = (W + 8 * hmax - 1) / (8 * hmax); mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+      for (auto& c : comps) {
+        c.pw = mcux * 8 * c.h; c.ph = mcuy * 8 * c.v;
+        // blocks that hold picture samples: a scan of this component alone codes only these
+        c.bw = ((W * c.h + hmax - 1) / hmax + 7) / 8; c.bh = ((H * c.v + vmax - 1) / vmax + 7) / 8;
+        c.coef.assign((size_t)c.pw * c.ph, 0);
+      }
       have_frame = true;
-    } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
-      err = "progressive, lossless and arithmetic-coded JPEG files are not supported (baseline is)";
+    } else if (m >= 0xc3 && m <= 0xcf && m != 0xc8 && m != 0xcc) {
+      err = "lossless, hierarchical and arithmetic-coded JPEG files are not supported";
       return false;
     } else if (m == 0xdd) {
       if (qe - q >= 2) restart = (q[0] << 8) | q[1];
     } else if (m == 0xda) {
       if (!have_frame) { err = "JPEG scan before its frame header"; return false; }
-      int ns = q[0];
-      if (ns != (int)comps.size() || qe - q < 1 + 2 * ns + 3) { err = "JPEG with one interleaved scan expected"; return false; }
+      const int ns = q[0];
+      if (ns < 1 || ns > (int)comps.size() || qe - q < 1 + 2 * ns + 3) { err = "bad JPEG scan header"; return false; }
+      Comp* sc[3];
       for (int k = 0; k < ns; ++k) {
-        int id = q[1 + 2 * k];
-        bool ok = false;
+        sc[k] = nullptr;
         for (auto& c : comps)
-          if (c.id == id) { c.td = q[2 + 2 * k] >> 4; c.ta = q[2 + 2 * k] & 15; ok = c.td < 4 && c.ta < 4 && hdc[c.td].set && hac[c.ta].set; }
-        if (!ok) { err = "bad JPEG scan header"; return false; }
+          if (c.id == q[1 + 2 * k]) { c.td = q[2 + 2 * k] >> 4; c.ta = q[2 + 2 * k] & 15; sc[k] = &c; }
+        if (!sc[k] || sc[k]->td > 3 || sc[k]->ta > 3) { err = "bad JPEG scan header"; return false; }
       }
-      int hmax = 1, vmax = 1;
-      for (auto& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
-      if (comps.size() == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }
-      const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
-      for (auto& c : comps) { c.pw = mcux * 8 * c.h; c.ph = mcuy * 8 * c.v; c.plane.assign((size_t)c.pw * c.ph, 0); c.pred = 0; }
+      int ss = q[1 + 2 * ns], se = q[2 + 2 * ns], ah = q[3 + 2 * ns] >> 4, al = q[3 + 2 * ns] & 15;
+      if (!progressive) { ss = 0; se = 63; ah = al = 0; }
+      if (ss > se || se > 63 || al > 13 || ah > 13 || (ss == 0 && se != 0 && progressive) || (ss > 0 && ns != 1)) {
+        err = "bad JPEG spectral selection"; return false;
+      }
+      for (int k = 0; k < ns; ++k) {
+        const bool need_dc = ss == 0 && ah == 0, need_ac = se > 0;
+        if ((need_dc && !hdc[sc[k]->td].set) || (need_ac && !hac[sc[k]->ta].set)) { err = "JPEG scan without its Huffman table"; return false; }
+        sc[k]->pred = 0;
+      }
       JpegBits br{p, n, at + len};
-      int until_restart = restart;
-      for (int my = 0; my < mcuy; ++my)
-        for (int mx = 0; mx < mcux; ++mx) {
-          if (restart && until_restart == 0) {
-            // the restart marker follows the byte-aligned data of the interval
-            br.reset();
-            while (br.at + 1 < n && !(p[br.at] == 0xff && p[br.at + 1] >= 0xd0 && p[br.at + 1] <= 0xd7)) ++br.at;
-            br.at += 2;
-            for (auto& c : comps) c.pred = 0;
-            until_restart = restart;
+      int eobrun = 0;
+      bool bad = false;
+      // one block of one scan; b points at the block's 64 coefficients
+      auto block = [&](Comp& c, int* b) {
+        if (!progressive) {
+          int t = jpeg_decode(br, hdc[c.td]);
+          if (t < 0 || t > 11) { bad = true; return; }
+          c.pred += jpeg_extend(br.receive(t), t);
+          b[0] = c.pred;
+          for (int k = 1; k < 64;) {
+            int rs = jpeg_decode(br, hac[c.ta]);
+            if (rs < 0) { bad = true; return; }
+            int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+            k += r;
+            if (k > 63) { bad = true; return; }
+            b[k++] = jpeg_extend(br.receive(sz), sz);
           }
-          --until_restart;
-          for (auto& c : comps)
-            for (int by = 0; by < c.v; ++by)
-              for (int bx = 0; bx < c.h; ++bx) {
-                float coef[64] = {0};
-                int t = jpeg_decode(br, hdc[c.td]);
-                if (t < 0 || t > 11) { err = "bad JPEG entropy data"; return false; }
-                c.pred += jpeg_extend(br.receive(t), t);
-                coef[0] = (float)(c.pred * qt[c.tq][0]);
-                for (int k = 1; k < 64;) {
-                  int rs = jpeg_decode(br, hac[c.ta]);
-                  if (rs < 0) { err = "bad JPEG entropy data"; return false; }
-                  int r = rs >> 4, sz = rs & 15;
-                  if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
-                  k += r;
-                  if (k > 63) { err = "bad JPEG entropy data"; return false; }
-                  coef[zigzag[k]] = (float)(jpeg_extend(br.receive(sz), sz) * qt[c.tq][k]);
-                  ++k;
-                }
-                float tmp[64];
-                for (int y = 0; y < 8; ++y)      // rows
-                  for (int x = 0; x < 8; ++x) {
-                    float a = 0.f;
-                    for (int u = 0; u < 8; ++u) a += cosv[x][u] * coef[y * 8 + u];
-                    tmp[y * 8 + x] = a * 0.5f;
-                  }
-                uint8_t* dst = c.plane.data() + (size_t)((my * c.v + by) * 8) * c.pw + (size_t)(mx * c.h + bx) * 8;
-                for (int x = 0; x < 8; ++x)      // columns
-                  for (int y = 0; y < 8; ++y) {
-                    float a = 0.f;
-                    for (int v = 0; v < 8; ++v) a += cosv[y][v] * tmp[v * 8 + x];
-                    float val = a * 0.5f + 128.f;
-                    dst[(size_t)y * c.pw + x] = (uint8_t)(val < 0.f ? 0 : val > 255.f ? 255 : (int)(val + 0.5f));
-                  }
+        } else if (ss == 0) {
+          if (ah == 0) {               // first pass over the DC coefficients
+            int t = jpeg_decode(br, hdc[c.td]);
+            if (t < 0 || t > 11) { bad = true; return; }
+            c.pred += jpeg_extend(br.receive(t), t);
+            b[0] = c.pred * (1 << al);
+          } else if (br.bit()) b[0] |= 1 << al;   // one more bit of each
+        } else if (ah == 0) {          // first pass over a band of AC coefficients
+          if (eobrun > 0) { --eobrun; return; }
+          for (int k = ss; k <= se;) {
+            int rs = jpeg_decode(br, hac[c.ta]);
+            if (rs < 0) { bad = true; return; }
+            int r = rs >> 4, sz = rs & 15;
+            if (sz == 0) {
+              if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += br.receive(r); break; }
+              k += 16;
+            } else {
+              k += r;
+              if (k > se) { bad = true; return; }
+              b[k++] = jpeg_extend(br.receive(sz), sz) * (1 << al);
+            }
+          }
+        } else {                       // one more bit of a band of AC coefficients
+          const int bit = 1 << al;
+          auto refine = [&](int& v) {
+            if (br.bit() && (v & bit) == 0) v += v > 0 ? bit : -bit;
+          };
+          if (eobrun > 0) {
+            --eobrun;
+            for (int k = ss; k <= se; ++k) if (b[k]) refine(b[k]);
+            return;
+          }
+          for (int k = ss; k <= se;) {
+            int rs = jpeg_decode(br, hac[c.ta]);
+            if (rs < 0) { bad = true; return; }
+            int r = rs >> 4, sz = rs & 15, val = 0;
+            if (sz == 0) {
+              if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += br.receive(r); r = 64; }  // the rest of the block only refines
+            } else {
+              if (sz != 1) { bad = true; return; }
+              val = br.bit() ? bit : -bit;
+            }
+            while (k <= se) {          // skip r zero coefficients, refining the others on the way
+              int& v = b[k++];
+              if (v) refine(v);
+              else {
+                if (r == 0) { v = val; break; }
+                --r;
               }
+            }
+          }
         }
-      // chroma up to full resolution with a triangle filter (sample centres of a 2:1 plane sit
-      // between the luma samples), then YCbCr -> RGB
-      im.w = W; im.h = H; im.comp = (int)comps.size();
-      im.px.assign((size_t)W * H * im.comp, 0);
-      auto sample = [&](const Comp& c, int x, int y) -> float {
-        auto at1 = [](int i, int f, int lim, float& w) -> int {   // position of full-res index i in a plane subsampled by f
-          if (f == 1) { w = 0.f; return i; }
-          float pos = (i + 0.5f) / f - 0.5f;
-          int i0 = (int)floorf(pos);
-          w = pos - i0;
-          (void)lim;
-          return i0;
-        };
-        int fx = hmax / c.h, fy = vmax / c.v;
-        float wx, wy;
-        int x0 = at1(x, fx, c.pw, wx), y0 = at1(y, fy, c.ph, wy);
-        int cw = (W + fx - 1) / fx, chh = (H + fy - 1) / fy;
-        auto px = [&](int xx, int yy) -> float {
-          xx = xx < 0 ? 0 : xx >= cw ? cw - 1 : xx;
-          yy = yy < 0 ? 0 : yy >= chh ? chh - 1 : yy;
-          return (float)c.plane[(size_t)yy * c.pw + xx];
-        };
-        if (fx == 1 && fy == 1) return px(x0, y0);
-        return (1 - wy) * ((1 - wx) * px(x0, y0) + wx * px(x0 + 1, y0)) + wy * ((1 - wx) * px(x0, y0 + 1) + wx * px(x0 + 1, y0 + 1));
       };
-      auto clamp8 = [](float v) -> uint8_t { return (uint8_t)(v < 0.f ? 0 : v > 255.f ? 255 : (int)(v + 0.5f)); };
-      for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) {
-          uint8_t* o = im.px.data() + ((size_t)y * W + x) * im.comp;
-          float Y = sample(comps[0], x, y);
-          if (im.comp == 1) { o[0] = clamp8(Y); continue; }
-          float cb = sample(comps[1], x, y) - 128.f, cr = sample(comps[2], x, y) - 128.f;
-          o[0] = clamp8(Y + 1.402f * cr);
-          o[1] = clamp8(Y - 0.344136f * cb - 0.714136f * cr);
-          o[2] = clamp8(Y + 1.772f * cb);
+      int until_restart = restart;
+      auto at_restart = [&]() {
+        if (restart && until_restart == 0) {
+          // the restart marker follows the byte-aligned data of the interval
+          br.reset();
+          while (br.at + 1 < n && !(p[br.at] == 0xff && p[br.at + 1] >= 0xd0 && p[br.at + 1] <= 0xd7)) ++br.at;
+          br.at += 2;
+          for (int k = 0; k < ns; ++k) sc[k]->pred = 0;
+          eobrun = 0;
+          until_restart = restart;
         }
-      return true;
+        --until_restart;
+      };
+      if (ns == 1) {                   // one component: its blocks in raster order
+        Comp& c = *sc[0];
+        const int row_blocks = c.pw / 8;
+        for (int by = 0; by < c.bh && !bad; ++by)
+          for (int bx = 0; bx < c.bw && !bad; ++bx) {
+            at_restart();
+            block(c, c.coef.data() + ((size_t)by * row_blocks + bx) * 64);
+          }
+      } else {
+        for (int my = 0; my < mcuy && !bad; ++my)
+          for (int mx = 0; mx < mcux && !bad; ++mx) {
+            at_restart();
+            for (int k = 0; k < ns; ++k) {
+              Comp& c = *sc[k];
+              for (int by = 0; by < c.v; ++by)
+                for (int bx = 0; bx < c.h && !bad; ++bx)
+                  block(c, c.coef.data() + ((size_t)(my * c.v + by) * (c.pw / 8) + (mx * c.h + bx)) * 64);
+            }
+          }
+      }
+      if (bad) { err = "bad JPEG entropy data"; return false; }
+      have_scan = true;
+      at = br.at;
+      continue;
     }
     at += len;
   }
-  err = "JPEG file without image data";
-  return false;
+  if (!have_scan) { err = "JPEG file without image data"; return false; }
+
+  // coefficients -> samples: dequantise, inverse DCT (separable, float), level shift
+  float cosv[8][8];
+  for (int x = 0; x < 8; ++x)
+    for (int u = 0; u < 8; ++u) cosv[x][u] = (u == 0 ? 0.70710678118654752f : 1.f) * cosf((2 * x + 1) * u * 3.14159265358979323846f / 16.f);
+  for (auto& c : comps) {
+    c.plane.assign((size_t)c.pw * c.ph, 0);
+    const int row_blocks = c.pw / 8;
+    for (int by = 0; by < c.ph / 8; ++by)
+      for (int bx = 0; bx < row_blocks; ++bx) {
+        const int* b = c.coef.data() + ((size_t)by * row_blocks + bx) * 64;
+        float coef[64], tmp[64];
+        for (int k = 0; k < 64; ++k) coef[zigzag[k]] = (float)(b[k] * qt[c.tq][k]);
+        for (int y = 0; y < 8; ++y)      // rows
+          for (int x = 0; x < 8; ++x) {
+            float a = 0.f;
+            for (int u = 0; u < 8; ++u) a += cosv[x][u] * coef[y * 8 + u];
+            tmp[y * 8 + x] = a * 0.5f;
+          }
+        uint8_t* dst = c.plane.data() + (size_t)(by * 8) * c.pw + (size_t)bx * 8;
+        for (int x = 0; x < 8; ++x)      // columns
+          for (int y = 0; y < 8; ++y) {
+            float a = 0.f;
+            for (int v = 0; v < 8; ++v) a += cosv[y][v] * tmp[v * 8 + x];
+            float val = a * 0.5f + 128.f;
+            dst[(size_t)y * c.pw + x] = (uint8_t)(val < 0.f ? 0 : val > 255.f ? 255 : (int)(val + 0.5f));
+          }
+      }
+  }
+  // chroma up to full resolution with a triangle filter (sample centres of a 2:1 plane sit
+  // between the luma samples), then YCbCr -> RGB
+  im.w = W; im.h = H; im.comp = (int)comps.size();
+  im.px.assign((size_t)W * H * im.comp, 0);
+  auto sample = [&](const Comp& c, int x, int y) -> float {
+    auto at1 = [](int i, int f, float& w) -> int {   // position of full-res index i in a plane subsampled by f
+      if (f == 1) { w = 0.f; return i; }
+      float pos = (i + 0.5f) / f - 0.5f;
+      int i0 = (int)floorf(pos);
+      w = pos - i0;
+      return i0;
+    };
+    int fx = hmax / c.h, fy = vmax / c.v;
+    float wx, wy;
+    int x0 = at1(x, fx, wx), y0 = at1(y, fy, wy);
+    int cw = (W + fx - 1) / fx, chh = (H + fy - 1) / fy;
+    auto px = [&](int xx, int yy) -> float {
+      xx = xx < 0 ? 0 : xx >= cw ? cw - 1 : xx;
+      yy = yy < 0 ? 0 : yy >= chh ? chh - 1 : yy;
+      return (float)c.plane[(size_t)yy * c.pw + xx];
+    };
+    if (fx == 1 && fy == 1) return px(x0, y0);
+    return (1 - wy) * ((1 - wx) * px(x0, y0) + wx * px(x0 + 1, y0)) + wy * ((1 - wx) * px(x0, y0 + 1) + wx * px(x0 + 1, y0 + 1));
+  };
+  auto clamp8 = [](float v) -> uint8_t { return (uint8_t)(v < 0.f ? 0 : v > 255.f ? 255 : (int)(v + 0.5f)); };
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      uint8_t* o = im.px.data() + ((size_t)y * W + x) * im.comp;
+      float Y = sample(comps[0], x, y);
+      if (im.comp == 1) { o[0] = clamp8(Y); continue; }
+      float cb = sample(comps[1], x, y) - 128.f, cr = sample(comps[2], x, y) - 128.f;
+      o[0] = clamp8(Y + 1.402f * cr);
+      o[1] = clamp8(Y - 0.344136f * cb - 0.714136f * cr);
+      o[2] = clamp8(Y + 1.772f * cb);
+    }
+  return true;
 }
 
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }

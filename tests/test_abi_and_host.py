@@ -335,10 +335,13 @@ def test_obj_without_normals_gets_smooth_ones(caster, tmp_path):
                                             "scene": [{"mesh": "x.obj", "material": "m"}]}, [("x.obj", mixed)]))
 
 
-@pytest.mark.parametrize("subsampling,quality,mode,restart", [(0, 92, "RGB", 0), (2, 85, "RGB", 0), (1, 90, "RGB", 4), (0, 90, "L", 0)])
-def test_jpeg_textures(tmp_path, subsampling, quality, mode, restart):
+@pytest.mark.parametrize("subsampling,quality,mode,restart,progressive",
+                         [(0, 92, "RGB", 0, False), (2, 85, "RGB", 0, False), (1, 90, "RGB", 4, False), (0, 90, "L", 0, False),
+                          (0, 92, "RGB", 0, True), (2, 85, "RGB", 0, True), (1, 75, "RGB", 3, True), (0, 90, "L", 0, True)])
+def test_jpeg_textures(tmp_path, subsampling, quality, mode, restart, progressive):
     """The reference loads textures through stb_image, JPEG included (imageio.cpp:12-17).  A baseline
-    JPEG texture decodes to what Pillow makes of the same file, to the +-1 or 2 levels by which
+    or progressive (spectral selection and successive approximation, one scan per component for the AC
+    bands) JPEG texture decodes to what Pillow makes of the same file, to the +-1 or 2 levels by which
     decoders differ in their inverse DCT, chroma filter and colour conversion."""
     from PIL import Image
     import oracle_lib as ol
@@ -351,6 +354,8 @@ def test_jpeg_textures(tmp_path, subsampling, quality, mode, restart):
     kw = dict(quality=quality, subsampling=subsampling) if mode == "RGB" else dict(quality=quality)
     if restart:
         kw["restart_marker_blocks"] = restart
+    if progressive:
+        kw["progressive"] = True
     pil.save(str(tmp_path / "t.jpg"), "JPEG", **kw)
     Image.open(str(tmp_path / "t.jpg")).convert("RGB").save(str(tmp_path / "t.png"))
     tex = {}
@@ -369,12 +374,17 @@ def test_jpeg_textures(tmp_path, subsampling, quality, mode, restart):
     assert np.percentile(diff, 99) <= (4 if subsampling == 0 else 10), np.percentile(diff, 99)
 
 
-def test_progressive_jpeg_is_refused(caster, tmp_path):
+def test_arithmetic_coded_jpeg_is_refused(caster, tmp_path):
     from PIL import Image
-    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(str(tmp_path / "p.jpg"), "JPEG", progressive=True)
+    import io
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(buf, "JPEG")
+    blob = bytearray(buf.getvalue())
+    blob[blob.index(b"\xff\xc0") + 1] = 0xC9                       # SOF9: extended sequential, arithmetic coding
+    (tmp_path / "p.jpg").write_bytes(bytes(blob))
     doc = {"camera": {}, "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "p.jpg"}],
            "scene": [{"mesh": "q.obj", "material": "m"}]}
-    with pytest.raises(caster.CasterError, match="progressive"):
+    with pytest.raises(caster.CasterError, match="arithmetic"):
         caster.Scene(write_scene(tmp_path, doc, [("q.obj", QUAD)]))
 
 
