@@ -597,6 +597,185 @@ bool load_jpeg(const std::string& data, Image8& im, std::string& err) {
   return true;
 }
 
+// Bounds-checked little-endian cursor over a file image, for the BMP and TGA headers.
+struct LeReader {
+  const uint8_t* p; size_t n, at = 0; bool over = false;
+  uint32_t u8() { if (at >= n) { over = true; return 0; } return p[at++]; }
+  uint32_t u16() { uint32_t a = u8(); return a | (u8() << 8); }
+  uint32_t u32() { uint32_t a = u16(); return a | (u16() << 16); }
+  void skip(size_t k) { at += k; if (at > n) { at = n; over = true; } }
+};
+
+// A masked field of a 16/32-bit BMP pixel widened to 8 bits by repeating its bits, as
+// stb_image's stbi__shiftsigned does for fields of one to eight bits.
+inline int bmp_field(uint32_t v, uint32_t mask) {
+  if (!mask) return 0;
+  int lo = 0, bits = 0;
+  while (!((mask >> lo) & 1)) ++lo;
+  while (lo + bits < 32 && ((mask >> (lo + bits)) & 1)) ++bits;
+  uint32_t f = (v & mask) >> lo;
+  if (bits >= 8) return (int)(f >> (bits - 8));
+  uint32_t r = 0;
+  int have = 0;
+  while (have < 8) { r = (r << bits) | f; have += bits; }
+  return (int)(r >> (have - 8));
+}
+
+// Windows BMP as stb_image 2.19 reads it for the reference (imageio.cpp:15): 1/4/8-bit
+// palettes, 16/24/32-bit pixels with the default or BI_BITFIELDS masks, bottom-up or top-down;
+// three components unless an alpha mask exists; a 32-bit BI_RGB file whose fourth bytes are all
+// zero comes back opaque.  RLE files are refused, as there.
+bool load_bmp(const std::string& data, Image8& im, std::string& err) {
+  LeReader r{(const uint8_t*)data.data(), data.size()};
+  if (r.u8() != 'B' || r.u8() != 'M') { err = "not a BMP"; return false; }
+  r.skip(8);
+  const uint32_t offset = r.u32(), hsz = r.u32();
+  if (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124) { err = "unknown BMP header"; return false; }
+  int w, h;
+  if (hsz == 12) { w = (int)r.u16(); h = (int)r.u16(); } else { w = (int)r.u32(); h = (int)r.u32(); }
+  if (r.u16() != 1) { err = "bad BMP"; return false; }
+  const int bpp = (int)r.u16();
+  uint32_t mr = 0, mg = 0, mb = 0, ma = 0, all_a = 255;
+  if (hsz != 12) {
+    const uint32_t compress = r.u32();
+    if (compress == 1 || compress == 2) { err = "run-length encoded BMP is not supported"; return false; }
+    r.skip(20);
+    if (hsz == 40 || hsz == 56) {
+      if (hsz == 56) r.skip(16);
+      if (bpp == 16 || bpp == 32) {
+        if (compress == 0) {
+          if (bpp == 32) { mr = 0xffu << 16; mg = 0xffu << 8; mb = 0xffu; ma = 0xffu << 24; all_a = 0; }
+          else { mr = 31u << 10; mg = 31u << 5; mb = 31u; }
+        } else if (compress == 3) {
+          mr = r.u32(); mg = r.u32(); mb = r.u32();
+          if (mr == mg && mg == mb) { err = "bad BMP masks"; return false; }
+        } else { err = "bad BMP compression"; return false; }
+      }
+    } else {
+      mr = r.u32(); mg = r.u32(); mb = r.u32(); ma = r.u32();
+    }
+  }
+  const bool bottom_up = h > 0;
+  h = h < 0 ? -h : h;
+  if (w <= 0 || h <= 0 || (size_t)w * h > (1u << 28) || r.over) { err = "bad BMP header"; return false; }
+  im.w = w; im.h = h; im.comp = ma ? 4 : 3;
+  im.px.assign((size_t)w * h * im.comp, 255);
+  auto out_row = [&](int j) { return im.px.data() + (size_t)(bottom_up ? h - 1 - j : j) * w * im.comp; };
+  if (bpp < 16) {
+    if (bpp != 1 && bpp != 4 && bpp != 8) { err = "bad BMP bit depth"; return false; }
+    if (bpp == 1 && ma) { err = "1-bit BMP with an alpha mask"; return false; }
+    const int esz = hsz == 12 ? 3 : 4;
+    // (stb_image 2.19 counts four entries too few under a 12-byte header and leaves them
+    // uninitialised; here the whole palette is read)
+    const long psize = hsz == 12 ? ((long)offset - 14 - 12) / 3 : ((long)offset - 14 - (long)hsz) >> 2;
+    if (psize <= 0 || psize > 256) { err = "bad BMP palette"; return false; }
+    uint8_t pal[256][3] = {{0}};
+    r.at = 14 + hsz;
+    for (long i = 0; i < psize; ++i) { pal[i][2] = (uint8_t)r.u8(); pal[i][1] = (uint8_t)r.u8(); pal[i][0] = (uint8_t)r.u8(); if (esz == 4) r.u8(); }
+    r.at = offset;
+    const int row_bytes = (w * bpp + 7) / 8, pad = (-row_bytes) & 3;
+    for (int j = 0; j < h; ++j) {
+      uint8_t* o = out_row(j);
+      if (r.at + (size_t)row_bytes > r.n) { err = "truncated BMP"; return false; }
+      const uint8_t* row = r.p + r.at;
+      r.skip((size_t)row_bytes + pad);
+      for (int i = 0; i < w; ++i) {
+        int v = bpp == 8 ? row[i] : bpp == 4 ? (row[i >> 1] >> ((i & 1) ? 0 : 4)) & 15 : (row[i >> 3] >> (7 - (i & 7))) & 1;
+        o[i * im.comp] = pal[v][0]; o[i * im.comp + 1] = pal[v][1]; o[i * im.comp + 2] = pal[v][2];
+      }
+    }
+    return true;
+  }
+  if (bpp != 16 && bpp != 24 && bpp != 32) { err = "bad BMP bit depth"; return false; }
+  const int easy = bpp == 24 ? 1 : (bpp == 32 && mb == 0xff && mg == 0xff00 && mr == 0x00ff0000 && ma == 0xff000000u) ? 2 : 0;
+  if (!easy && (!mr || !mg || !mb)) { err = "bad BMP masks"; return false; }
+  const int px_bytes = bpp / 8, pad = bpp == 32 ? 0 : (-(w * px_bytes)) & 3;
+  r.at = offset;
+  if ((size_t)offset + ((size_t)w * px_bytes + pad) * (size_t)h - pad > r.n) { err = "truncated BMP"; return false; }
+  for (int j = 0; j < h; ++j) {
+    uint8_t* o = out_row(j);
+    for (int i = 0; i < w; ++i, o += im.comp) {
+      uint32_t a;
+      if (easy) {
+        o[2] = (uint8_t)r.u8(); o[1] = (uint8_t)r.u8(); o[0] = (uint8_t)r.u8();
+        a = easy == 2 ? r.u8() : 255;
+      } else {
+        const uint32_t v = bpp == 16 ? r.u16() : r.u32();
+        o[0] = (uint8_t)bmp_field(v, mr); o[1] = (uint8_t)bmp_field(v, mg); o[2] = (uint8_t)bmp_field(v, mb);
+        a = ma ? (uint32_t)bmp_field(v, ma) : 255;
+      }
+      all_a |= a;
+      if (im.comp == 4) o[3] = (uint8_t)a;
+    }
+    r.skip(pad);
+  }
+  if (im.comp == 4 && all_a == 0)
+    for (size_t i = 3; i < im.px.size(); i += 4) im.px[i] = 255;
+  return true;
+}
+
+// Truevision TGA as stb_image 2.19 reads it for the reference (imageio.cpp:15): grey, 15/16-bit
+// (five bits a channel, no alpha), 24 and 32-bit pixels, raw or run-length packets, direct or
+// through a colour map, rows bottom-up unless bit 5 of the descriptor says top-down.  16-bit grey
+// (grey+alpha) is refused: the reference has no branch for two components.
+bool load_tga(const std::string& data, Image8& im, std::string& err) {
+  LeReader r{(const uint8_t*)data.data(), data.size()};
+  const int id_len = (int)r.u8(), indexed = (int)r.u8();
+  int type = (int)r.u8();
+  const int pal_start = (int)r.u16(), pal_len = (int)r.u16(), pal_bits = (int)r.u8();
+  r.skip(4);
+  const int w = (int)r.u16(), h = (int)r.u16(), bpp = (int)r.u8(), desc = (int)r.u8();
+  const bool rle = type >= 8;
+  if (rle) type -= 8;
+  if (r.over || indexed > 1 || (indexed ? type != 1 : (type != 2 && type != 3)) || w <= 0 || h <= 0) { err = "not a TGA (or an image format that is not supported)"; return false; }
+  const int fmt_bits = indexed ? pal_bits : bpp;
+  const bool rgb16 = fmt_bits == 15 || (fmt_bits == 16 && !(type == 3 && !indexed));
+  const int comp = fmt_bits == 8 ? 1 : rgb16 ? 3 : (fmt_bits == 24 || fmt_bits == 32) ? fmt_bits / 8 : 0;
+  if (fmt_bits == 16 && !rgb16) { err = "grey+alpha TGA (the reference reads two-component images as garbage)"; return false; }
+  if (!comp || (indexed && bpp != 8 && bpp != 16)) { err = "unsupported TGA pixel format"; return false; }
+  auto rgb16_to = [](uint32_t px, uint8_t* o) {
+    o[0] = (uint8_t)((((px >> 10) & 31) * 255) / 31); o[1] = (uint8_t)((((px >> 5) & 31) * 255) / 31); o[2] = (uint8_t)(((px & 31) * 255) / 31);
+  };
+  r.skip((size_t)id_len);
+  std::vector<uint8_t> pal;
+  if (indexed) {
+    r.skip((size_t)pal_start);
+    pal.assign((size_t)std::max(pal_len, 1) * comp, 0);
+    for (int i = 0; i < pal_len; ++i) {
+      if (rgb16) rgb16_to(r.u16(), pal.data() + (size_t)i * comp);
+      else for (int j = 0; j < comp; ++j) pal[(size_t)i * comp + j] = (uint8_t)r.u8();
+    }
+  }
+  im.w = w; im.h = h; im.comp = comp;
+  im.px.assign((size_t)w * h * comp, 0);
+  const bool bottom_up = !((desc >> 5) & 1);
+  uint8_t raw[4] = {0, 0, 0, 0};
+  int count = 0;
+  bool repeating = false, read_next = true;
+  for (size_t i = 0; i < (size_t)w * h; ++i) {
+    if (rle) {
+      if (count == 0) { const uint32_t cmd = r.u8(); count = 1 + (int)(cmd & 127); repeating = cmd >> 7; read_next = true; }
+      else if (!repeating) read_next = true;
+    } else read_next = true;
+    if (read_next) {
+      if (indexed) {
+        uint32_t idx = bpp == 8 ? r.u8() : r.u16();
+        if ((int)idx >= pal_len) idx = 0;
+        memcpy(raw, pal.data() + (size_t)idx * comp, (size_t)comp);
+      } else if (rgb16) rgb16_to(r.u16(), raw);
+      else for (int j = 0; j < comp; ++j) raw[j] = (uint8_t)r.u8();
+      read_next = false;
+    }
+    const size_t y = i / w, x = i % w;
+    uint8_t* o = im.px.data() + ((bottom_up ? (size_t)h - 1 - y : y) * w + x) * comp;
+    memcpy(o, raw, (size_t)comp);
+    if (comp >= 3 && !rgb16) std::swap(o[0], o[2]);   // stored blue first
+    --count;
+  }
+  if (r.over) { err = "truncated TGA"; return false; }
+  return true;
+}
+
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
 
 // Undo the per-row PNG filters of one (sub-)image in place: `rows` rows of
@@ -758,8 +937,12 @@ bool load_texture_file(const std::string& path, Texture& out, std::string& err) 
   Image8 im;
   if (!load_ppm(data, im)) {
     std::string perr;
+    // by content, in stb_image's order: JPEG, PNG, BMP, and TGA (which has no signature) last
     const bool jpeg = data.size() > 2 && (uint8_t)data[0] == 0xff && (uint8_t)data[1] == 0xd8;
-    if (jpeg ? !load_jpeg(data, im, perr) : !load_png(data, im, perr)) { err = "texture \"" + path + "\": " + perr; return false; }
+    const bool png = data.size() > 4 && (uint8_t)data[0] == 0x89 && data[1] == 'P';
+    const bool bmp = data.size() > 2 && data[0] == 'B' && data[1] == 'M';
+    const bool ok = jpeg ? load_jpeg(data, im, perr) : png ? load_png(data, im, perr) : bmp ? load_bmp(data, im, perr) : load_tga(data, im, perr);
+    if (!ok) { err = "texture \"" + path + "\": " + perr; return false; }
   }
   out.w = im.w; out.h = im.h;
   out.rgba.resize((size_t)im.w * im.h * 4);

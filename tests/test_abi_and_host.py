@@ -520,3 +520,154 @@ def test_png_refusals(caster, tmp_path):
         (tmp_path / "t.png").write_bytes(blob)
         with pytest.raises(caster.CasterError, match=needle):
             caster.Scene(write_scene(tmp_path, doc, [("q.obj", QUAD)]))
+
+
+def _texels(tmp_path, name, blob):
+    """The oracle-side texture (same loader as the library) of a one-texture scene holding `blob`."""
+    import oracle_lib as ol
+    d = tmp_path / name.replace(".", "_")
+    d.mkdir()
+    (d / name).write_bytes(blob)
+    doc = {"camera": {}, "material": [{"name": "m", "bsdf": "lambertian", "diffuse": name}],
+           "scene": [{"mesh": "q.obj", "material": "m"}]}
+    return ol.Oracle(write_scene(d, doc, [("q.obj", QUAD)])).texture(0)
+
+
+def _as_png(arr):
+    from PIL import Image
+    import io
+    buf = io.BytesIO()
+    Image.fromarray(arr.astype(np.uint8), {3: "RGB", 4: "RGBA"}[arr.shape[2]]).save(buf, "PNG")
+    return buf.getvalue()
+
+
+def _bmp_bytes(pixels, bpp, masks=None, top_down=False, palette=None, header=40):
+    """A BMP written here so that bit depths, masks, row order and header sizes can be asked for.
+    `pixels` holds packed pixel values (h, w) for 16/32 bit and palette indices below that, or
+    (h, w, 3) B,G,R bytes for 24 bit."""
+    import struct
+    h, w = pixels.shape[:2]
+    rows = []
+    for y in (range(h) if top_down else range(h - 1, -1, -1)):
+        if bpp == 24:
+            line = pixels[y].astype(np.uint8).tobytes()
+        elif bpp in (16, 32):
+            line = pixels[y].astype("<u2" if bpp == 16 else "<u4").tobytes()
+        elif bpp == 8:
+            line = pixels[y].astype(np.uint8).tobytes()
+        else:
+            per = 8 // bpp
+            padded = np.zeros((w + per - 1) // per * per, np.int64)
+            padded[:w] = pixels[y]
+            acc = np.zeros(len(padded) // per, np.int64)
+            for k in range(per):
+                acc = (acc << bpp) | padded[k::per]
+            line = acc.astype(np.uint8).tobytes()
+        rows.append(line + b"\0" * (-len(line) % 4))
+    body = b"".join(rows)
+    pal = b"" if palette is None else b"".join(bytes([int(c[2]), int(c[1]), int(c[0])]) + (b"" if header == 12 else b"\0") for c in palette)
+    if header == 12:
+        info = struct.pack("<IHHHH", 12, w, h, 1, bpp)
+    else:
+        info = struct.pack("<IiiHHIIiiII", header, w, -h if top_down else h, 1, bpp, 3 if masks else 0, len(body), 2835, 2835, 0, 0)
+        if header == 40 and masks:
+            info += struct.pack("<III", *masks[:3])
+        elif header > 40:
+            info += struct.pack("<IIII", *(masks or (0, 0, 0, 0))) + b"\0" * (header - 56)
+    offset = 14 + len(info) + len(pal)
+    return b"BM" + struct.pack("<IHHI", offset + len(body), 0, 0, offset) + info + pal + body
+
+
+def test_bmp_textures(caster, tmp_path):
+    """BMP files give the texels stb_image 2.19 hands the reference (imageio.cpp:15): palettes of 1, 4 and
+    8 bits, 24-bit B,G,R, 16- and 32-bit pixels with default or explicit masks (fields widened by bit
+    repetition), bottom-up and top-down rows; Pillow's own BMP files too."""
+    from PIL import Image
+    import io
+    rng = np.random.RandomState(11)
+    w, h = 13, 9
+    rgb = rng.randint(0, 256, size=(h, w, 3))
+    want = _texels(tmp_path, "want.png", _as_png(rgb))
+    assert np.array_equal(_texels(tmp_path, "a24.bmp", _bmp_bytes(rgb[:, :, ::-1], 24)), want)
+    assert np.array_equal(_texels(tmp_path, "a24t.bmp", _bmp_bytes(rgb[:, :, ::-1], 24, top_down=True)), want)
+    buf = io.BytesIO()
+    Image.fromarray(rgb.astype(np.uint8), "RGB").save(buf, "BMP")
+    assert np.array_equal(_texels(tmp_path, "pil24.bmp", buf.getvalue()), want)
+    # 32 bit, BI_RGB: the fourth byte is alpha, unless it is zero everywhere
+    alpha = rng.randint(1, 256, size=(h, w))
+    packed = (alpha.astype(np.int64) << 24) | (rgb[:, :, 0] << 16) | (rgb[:, :, 1] << 8) | rgb[:, :, 2]
+    want_a = _texels(tmp_path, "wanta.png", _as_png(np.concatenate([rgb, alpha[:, :, None]], axis=2)))
+    assert np.array_equal(_texels(tmp_path, "a32.bmp", _bmp_bytes(packed, 32)), want_a)
+    assert np.array_equal(_texels(tmp_path, "a32z.bmp", _bmp_bytes(packed & 0xFFFFFF, 32)), want)
+    # explicit masks in a V4 header, in another order
+    packed2 = (rgb[:, :, 2].astype(np.int64) << 24) | (rgb[:, :, 1] << 16) | (rgb[:, :, 0] << 8) | alpha
+    assert np.array_equal(_texels(tmp_path, "a32m.bmp", _bmp_bytes(packed2, 32, masks=(0xFF00, 0xFF0000, 0xFF000000, 0xFF), header=108)), want_a)
+    # 16 bit: 5-5-5 by default, 5-6-5 with masks; fields widen by repeating their bits
+    r5, g6, b5 = rng.randint(0, 32, size=(h, w)), rng.randint(0, 64, size=(h, w)), rng.randint(0, 32, size=(h, w))
+    g5 = g6 >> 1
+    wide5 = lambda v: (v << 3) | (v >> 2)
+    want555 = _texels(tmp_path, "w555.png", _as_png(np.stack([wide5(r5), wide5(g5), wide5(b5)], axis=2)))
+    want565 = _texels(tmp_path, "w565.png", _as_png(np.stack([wide5(r5), (g6 << 2) | (g6 >> 4), wide5(b5)], axis=2)))
+    assert np.array_equal(_texels(tmp_path, "a555.bmp", _bmp_bytes((r5 << 10) | (g5 << 5) | b5, 16)), want555)
+    assert np.array_equal(_texels(tmp_path, "a565.bmp", _bmp_bytes((r5 << 11) | (g6 << 5) | b5, 16, masks=(0xF800, 0x07E0, 0x001F))), want565)
+    # palettes
+    for bpp, hdr in ((8, 40), (4, 40), (1, 40), (8, 12), (4, 12)):
+        pal = rng.randint(0, 256, size=(2 ** bpp, 3))
+        idx = rng.randint(0, 2 ** bpp, size=(h, w))
+        got = _texels(tmp_path, "p%d_%d.bmp" % (bpp, hdr), _bmp_bytes(idx, bpp, palette=pal, header=hdr, top_down=(bpp == 4 and hdr == 40)))
+        assert np.array_equal(got, _texels(tmp_path, "wp%d_%d.png" % (bpp, hdr), _as_png(pal[idx])))
+    buf = io.BytesIO()
+    Image.fromarray(rgb[:, :, 0].astype(np.uint8), "L").save(buf, "BMP")
+    assert np.array_equal(_texels(tmp_path, "pilL.bmp", buf.getvalue()), _texels(tmp_path, "wl.png", _as_png(np.repeat(rgb[:, :, :1], 3, axis=2))))
+    # refusals
+    doc = {"camera": {}, "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "t.bmp"}], "scene": [{"mesh": "q.obj", "material": "m"}]}
+    rle = bytearray(_bmp_bytes(rng.randint(0, 256, size=(h, w)), 8, palette=rng.randint(0, 256, size=(256, 3))))
+    rle[30] = 1
+    for blob, needle in ((bytes(rle), "run-length"), (_bmp_bytes(rgb[:, :, ::-1], 24)[:100], "truncated")):
+        (tmp_path / "t.bmp").write_bytes(blob)
+        with pytest.raises(caster.CasterError, match=needle):
+            caster.Scene(write_scene(tmp_path, doc, [("q.obj", QUAD)]))
+
+
+@pytest.mark.parametrize("mode", ["L", "RGB", "RGBA", "P"])
+@pytest.mark.parametrize("rle", [False, True])
+@pytest.mark.parametrize("orientation", [-1, 1])
+def test_tga_textures(tmp_path, mode, rle, orientation):
+    """TGA files as Pillow writes them (grey, 24/32 bit, colour-mapped; raw or run-length packets;
+    bottom-up or top-down) give the texels of the same picture as a PNG."""
+    from PIL import Image
+    import io
+    rng = np.random.RandomState(3)
+    w, h = 21, 10
+    base = rng.randint(0, 256, size=(h, w, 4))
+    base[2:5, 3:15] = base[2, 3]                                    # runs, also across a row end
+    base[6, 10:] = base[6, 10]
+    base[7, :6] = base[6, 10]
+    img = Image.fromarray(base.astype(np.uint8), "RGBA")
+    if mode == "P":
+        img = img.convert("RGB").quantize(16)
+        want = np.asarray(img.convert("RGB"))
+    else:
+        img = img.convert(mode)
+        want = np.asarray(img)
+        want = np.repeat(want[:, :, None], 3, axis=2) if mode == "L" else want
+    buf = io.BytesIO()
+    img.save(buf, "TGA", compression="tga_rle" if rle else None, orientation=orientation)
+    assert np.array_equal(_texels(tmp_path, "t.tga", buf.getvalue()), _texels(tmp_path, "w.png", _as_png(want)))
+
+
+def test_tga_16_bit_and_refusals(caster, tmp_path):
+    import struct
+    rng = np.random.RandomState(4)
+    w, h = 7, 5
+    r5, g5, b5 = (rng.randint(0, 32, size=(h, w)) for _ in range(3))
+    px = ((r5 << 10) | (g5 << 5) | b5).astype("<u2")
+    head = struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, w, h, 16, 0x20)       # top-down
+    want = np.stack([(r5 * 255) // 31, (g5 * 255) // 31, (b5 * 255) // 31], axis=2)
+    assert np.array_equal(_texels(tmp_path, "a16.tga", head + px.tobytes()), _texels(tmp_path, "w.png", _as_png(want)))
+    doc = {"camera": {}, "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "t.tga"}], "scene": [{"mesh": "q.obj", "material": "m"}]}
+    grey_alpha = struct.pack("<BBBHHBHHHHBB", 0, 0, 3, 0, 0, 0, 0, 0, w, h, 16, 8) + px.tobytes()
+    for blob, needle in ((grey_alpha, "grey\\+alpha"), (head + px.tobytes()[:20], "truncated"), (b"GIF89a" + bytes(40), "not a TGA")):
+        (tmp_path / "t.tga").write_bytes(blob)
+        with pytest.raises(caster.CasterError, match=needle):
+            caster.Scene(write_scene(tmp_path, doc, [("q.obj", QUAD)]))
