@@ -37,6 +37,12 @@ SMALL_SCENES = {
     "car_lt": dict(name="car_pt", width=96, height=54, detail=0.01, integrator="lt"),
     "car_bdpt": dict(name="car_pt", width=96, height=54, detail=0.01, integrator="bdpt"),
     "stairs_bdpt": dict(name="stairs_pt", width=64, height=36, detail=0.08, integrator="bdpt"),
+    # emitters plus an environment map: the light choice can fall into the environment's bin
+    "car_env_lt": dict(name="car_pt", width=96, height=54, detail=0.01, env=True, integrator="lt"),
+    "car_env_bdpt": dict(name="car_pt", width=96, height=54, detail=0.01, env=True, integrator="bdpt"),
+    # the environment map alone: no emissive triangle to start a light path from
+    "car_envonly_lt": dict(name="car_pt", width=96, height=54, detail=0.01, env=True, integrator="lt", drop_emitters=True),
+    "car_envonly_bdpt": dict(name="car_pt", width=96, height=54, detail=0.01, env=True, integrator="bdpt", drop_emitters=True),
     "knot_pt": dict(name="knot_pt", width=96, height=96, detail=0.08),
     "stairs_pt": dict(name="stairs_pt", width=128, height=72, detail=0.08),
     "car_pt": dict(name="car_pt", width=128, height=72, detail=0.01),
@@ -54,10 +60,13 @@ def scenes(tmp_path_factory):
         kw = dict(kw)
         name = kw.pop("name")
         integrator = kw.pop("integrator", None)
+        drop_emitters = kw.pop("drop_emitters", False)
         out[key] = gen_scenes.generate(str(base / key), name, **kw)
         if integrator:   # the same scene under another of the reference's integrators
             import json
             doc = json.load(open(out[key]))
             doc["integrator"] = integrator
+            if drop_emitters:
+                doc["light"] = [l for l in doc["light"] if "infinite" in l]
             json.dump(doc, open(out[key], "w"))
     return out

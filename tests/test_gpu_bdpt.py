@@ -16,7 +16,8 @@ import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 
-SPP = {"cornell_bdpt": 6, "cornell_fog_bdpt": 4, "cornell_smoke_bdpt": 4, "car_bdpt": 4, "stairs_bdpt": 3}
+SPP = {"cornell_bdpt": 6, "cornell_fog_bdpt": 4, "cornell_smoke_bdpt": 4, "car_bdpt": 4, "stairs_bdpt": 3, "car_env_bdpt": 3,
+       "car_envonly_bdpt": 3}
 
 
 def rel(gpu, cpu):
@@ -59,7 +60,8 @@ def test_film_matches_oracle(caster, scenes, key):
     r.close()
     assert st["stack_overflow"] == 0 and st["samples"] == sc.width * sc.height * spp
     assert np.isfinite(gpu).all() and np.isfinite(cpu).all()
-    assert cpu.mean() > 1e-3 and gpu.mean() > 1e-3
+    if "envonly" not in key:   # no emissive triangle: whatever the reference's conventions leave, on both sides
+        assert cpu.mean() > 1e-3 and gpu.mean() > 1e-3
     check_close(gpu, cpu, key)
     # the same walks on both sides: sub-path rays and transmittance segments, one by one
     c = counts.as_dict()
