@@ -223,3 +223,40 @@ def test_render_tool_writes_the_film(caster, tmp_path):
     r.render(1, 5, True)
     np.testing.assert_array_equal(image, r.read_film(0))
     r.close()
+
+
+def _read_pfm(path):
+    head = open(path, "rb").read().split(b"\n", 3)
+    w, h = map(int, head[1].split())
+    return np.frombuffer(head[3], "<f4").reshape(h, w, 3)
+
+
+def test_render_tool_previews_and_ranks(tmp_path):
+    """tools/render.py --preview-every rewrites the image as the samples come in and ends on the image
+    of the plain run, bit for bit on one GPU (the film adds its iterations in the same order); two ranks
+    sharing the GPU (gloo, a rehearsal of the multi-GPU path) hand their films over at every preview and
+    end on the same mean up to the order of the float additions."""
+    import subprocess
+    import sys
+    key = sorted(VEC["scenes"])[0]
+    scene = os.path.join(GOLD, "scenes", key, "scene.json")
+    tool = os.path.join(ROOT, "tools", "render.py")
+    outs = {}
+    for name, extra, launcher in (("plain", [], []), ("preview", ["--preview-every", "2"], []),
+                                  ("ranks", ["--preview-every", "3", "--backend", "gloo", "--share-gpu"],
+                                   ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                    "--master-addr", "127.0.0.1", "--master-port", "29653"]),
+                                  ("tiles", ["--preview-every", "4", "--shard", "tile", "--backend", "gloo", "--share-gpu"],
+                                   ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                    "--master-addr", "127.0.0.1", "--master-port", "29654"])):
+        outs[name] = str(tmp_path / (name + ".pfm"))
+        p = subprocess.run([sys.executable] + launcher + [tool, scene, "--spp", "7", "--iters-in-flight", "2", "--out", outs[name]] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        if extra:
+            assert "preview:" in p.stdout
+    plain = _read_pfm(outs["plain"])
+    assert plain.mean() > 0.01
+    np.testing.assert_array_equal(_read_pfm(outs["preview"]), plain)
+    for name in ("ranks", "tiles"):
+        np.testing.assert_allclose(_read_pfm(outs[name]), plain, rtol=2e-6, atol=1e-7)

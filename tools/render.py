@@ -9,6 +9,10 @@ One process per GPU.  With several ranks the iterations (``--shard spp``) or ban
 (``--shard tile``) are split over the ranks (cuda-pathtracer_amd/sharding.py) and the films meet on
 rank 0 in one RCCL reduce, which then writes the image: .png is tonemapped as the reference's
 Output() + SavePng do, .exr and .pfm hold the linear mean.
+
+``--preview-every K`` rewrites the image after every K samples per pixel (the reference's window
+shows its running mean after every iteration, CudaRender.cpp:48-60): the ranks' films are reduced
+at each of those points, rank 0 keeps the running sum and the other ranks start their film afresh.
 """
 import argparse
 import importlib
@@ -28,6 +32,7 @@ def main():
     ap.add_argument("--shard", choices=["spp", "tile"], default="spp")
     ap.add_argument("--gpu-bvh", action="store_true", help="build the BVH on the GPU (same tree as the host build)")
     ap.add_argument("--iters-in-flight", type=int, default=0)
+    ap.add_argument("--preview-every", type=int, default=0, metavar="K", help="rewrite the image after every K samples per pixel")
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo + --share-gpu rehearses N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses device 0 (rehearsal only)")
     a = ap.parse_args()
@@ -48,36 +53,54 @@ def main():
     scene = caster.Scene(a.scene, build_device=dev if a.gpu_bvh else None)
     r = caster.Renderer(scene, dev, a.iters_in_flight)
     t0 = time.perf_counter()
-    if world > 1 and a.shard == "tile":
-        r.set_rows(*sharding.row_band(scene.height, rank, world))
-        blocks = [(1, a.spp)]
-    else:
-        block = max(1, min(64, a.spp // max(world, 1)))
-        blocks = sharding.spp_blocks(1, a.spp, block, rank, world)
-    first = True
-    for it, n in blocks:
-        r.render_async(it, n, first)
-        first = False
-    r.sync()
     tonemapped = a.out.lower().endswith(".png")
-    if world == 1:
-        r.save_image(a.out)
-    else:
+    if world > 1:
         import torch
         film = torch.zeros(scene.width * scene.height * 3, dtype=torch.float32, device="cuda:%d" % dev)
-        if not first:
-            r.read_film_device(film.data_ptr(), 2)
-        if a.backend == "nccl":
-            sharding.reduce_film(film, dist, 0)
-        else:  # films meet on the host
-            host = film.cpu()
-            sharding.reduce_film(host, dist, 0)
-            film.copy_(host)
-        if rank == 0:
-            # the summed film back into the renderer, which divides, tonemaps and writes it
-            r.render(1, 0, True)
-            r.film_add_device(film.data_ptr(), a.spp)
+    if world > 1 and a.shard == "tile":
+        r.set_rows(*sharding.row_band(scene.height, rank, world))
+    # samples per pixel between two images: all of them unless previews are asked for
+    step = a.spp if a.preview_every <= 0 else min(a.preview_every, a.spp)
+    done = 0
+    fresh = True          # this rank's film holds nothing yet
+    while done < a.spp:
+        n_round = min(step, a.spp - done)
+        if world > 1 and a.shard == "tile":
+            blocks = [(1 + done, n_round)]
+        else:
+            block = max(1, min(64, n_round // max(world, 1)))
+            blocks = sharding.spp_blocks(1 + done, n_round, block, rank, world)
+        for it, n in blocks:
+            r.render_async(it, n, fresh)
+            fresh = False
+        r.sync()
+        done += n_round
+        if world == 1:
             r.save_image(a.out)
+        else:
+            # the library works on its own streams, torch on another: meet on the host in between
+            if fresh:
+                film.zero_()
+                torch.cuda.synchronize(dev)
+            else:
+                r.read_film_device(film.data_ptr(), 2)
+            if a.backend == "nccl":
+                sharding.reduce_film(film, dist, 0)
+            else:  # films meet on the host
+                host = film.cpu()
+                sharding.reduce_film(host, dist, 0)
+                film.copy_(host)
+            torch.cuda.synchronize(dev)
+            if rank == 0:
+                # the summed film (rank 0's own included) back into the renderer, which divides,
+                # tonemaps and writes it, and keeps adding to it in the next round
+                r.render(1, 0, True)
+                r.film_add_device(film.data_ptr(), done)
+                r.save_image(a.out)
+            else:
+                fresh = True   # handed over: the next round starts from an empty film
+        if rank == 0 and done < a.spp:
+            print("preview: %d of %d spp after %.2f s -> %s" % (done, a.spp, time.perf_counter() - t0, a.out), flush=True)
     if rank == 0:
         dt = time.perf_counter() - t0
         print("%s: %dx%d, %d spp on %d GPU(s) in %.2f s (%.1f Msamples/s) -> %s%s" % (
