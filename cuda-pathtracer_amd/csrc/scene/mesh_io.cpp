@@ -376,6 +376,7 @@ bool load_jpeg(const std::string& data, Image8& im, std::string& err) {
       H = (q[1] << 8) | q[2]; W = (q[3] << 8) | q[4];
       int nc = q[5];
       if ((nc != 1 && nc != 3) || qe - q < 6 + 3 * nc || W <= 0 || H <= 0) { err = "JPEG with 1 or 3 components expected"; return false; }
+      if ((size_t)W * H > (1u << 28)) { err = "JPEG too large"; return false; }
       comps.resize((size_t)nc);
       for (int c = 0; c < nc; ++c) {
         comps[c].id = q[6 + 3 * c]; comps[c].h = q[7 + 3 * c] >> 4; comps[c].v = q[7 + 3 * c] & 15; comps[c].tq = q[8 + 3 * c] & 3;
@@ -727,7 +728,7 @@ bool load_tga(const std::string& data, Image8& im, std::string& err) {
   const int w = (int)r.u16(), h = (int)r.u16(), bpp = (int)r.u8(), desc = (int)r.u8();
   const bool rle = type >= 8;
   if (rle) type -= 8;
-  if (r.over || indexed > 1 || (indexed ? type != 1 : (type != 2 && type != 3)) || w <= 0 || h <= 0) { err = "not a TGA (or an image format that is not supported)"; return false; }
+  if (r.over || indexed > 1 || (indexed ? type != 1 : (type != 2 && type != 3)) || w <= 0 || h <= 0 || (size_t)w * h > (1u << 28)) { err = "not a TGA (or an image format that is not supported)"; return false; }
   const int fmt_bits = indexed ? pal_bits : bpp;
   const bool rgb16 = fmt_bits == 15 || (fmt_bits == 16 && !(type == 3 && !indexed));
   const int comp = fmt_bits == 8 ? 1 : rgb16 ? 3 : (fmt_bits == 24 || fmt_bits == 32) ? fmt_bits / 8 : 0;
@@ -1045,8 +1046,9 @@ bool load_exr(const std::string& data, Infinite& out, std::string& err) {
     }
     in.at = end;
   }
-  const int w = x1 - x0 + 1, h = y1 - y0 + 1;
-  if (w <= 0 || h <= 0 || chans.empty()) { err = "EXR header lacks channels or a data window"; return false; }
+  const long long w64 = (long long)x1 - x0 + 1, h64 = (long long)y1 - y0 + 1;
+  if (w64 <= 0 || h64 <= 0 || w64 * h64 > (1ll << 28) || chans.empty()) { err = "EXR header lacks channels or a data window"; return false; }
+  const int w = (int)w64, h = (int)h64;
   if (compression < 0 || compression > 3) {
     static const char* names[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
     err = std::string("EXR compression ") + (compression >= 0 && compression < 10 ? names[compression] : "?") +
