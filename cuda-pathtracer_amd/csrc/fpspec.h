@@ -39,6 +39,19 @@ CASTER_HD float rsqrt_(float x) { return 1.0f / sqrtf(x); }
 
 CASTER_HD float clamp_(float v, float lo, float hi) { return fmin_(fmax_(v, lo), hi); }
 
+// Slack of the slab test's near-plane cull.  The reference drops a box whose entry distance
+// exceeds the ray's tmax (CUDA-PathTracer/tracer/bbox.h:88-97: the far side is padded by
+// 1 + 2*gamma(3), the near side is not).  Two triangles that share the edge a ray hits report
+// the same distance, or distances a rounding apart, and once one of them has shortened the ray
+// the other's box can fail that test by a rounding error of the slab arithmetic: which of the two
+// is the closest hit then depends on the order the tree is walked in.  With the cull at
+// tmax * kNearCullSlack both are always tested, and the result (smallest t, among equal t the
+// highest primitive index) is the same for every traversal order -- which a wavefront traversal
+// whose order depends on its neighbours needs in order to be a function of the ray alone.  It
+// differs from the reference's own order-dependent choice in about one sample in 10^7 (a ray
+// through a shared edge), by the difference between the two triangles' interpolated normals.
+constexpr float kNearCullSlack = 1.0f + 1.0f / 65536.0f;
+
 // float -> int with every out-of-range case defined (x86 and gfx950 disagree
 // on NaN and overflow): NaN -> 0, saturating otherwise, truncation inside.
 CASTER_HD int f2i_(float v) {

@@ -67,12 +67,13 @@ __global__ void k_gather_ids(LaunchCtx L, RayQueue q, int32_t* ids) {
 // clears the queues that the next shade pass appends to.
 __global__ void k_roll(Stats* st, const uint32_t* n_ext, const uint32_t* n_shadow, const uint32_t* n_probe,
                        uint32_t* clear0, uint32_t* clear1, uint32_t* clear2, uint32_t ext_override, uint32_t* work,
-                       uint32_t n_work, uint32_t work_init) {
+                       uint32_t n_work, uint32_t work_init, uint32_t probes_in_shadow) {
   // work counters start at zero (k_trace adds the size of its static assignment itself)
   for (uint32_t i = 0; i < n_work; ++i) work[i * kWorkPad] = work_init;
   if (ext_override) st->rays[0] += ext_override;
   else if (n_ext) st->rays[0] += *n_ext;
-  if (n_shadow) st->rays[1] += *n_shadow;
+  // (probe rays traced among the shadow rays are counted as probe rays)
+  if (n_shadow) st->rays[1] += *n_shadow - (probes_in_shadow && n_probe ? *n_probe : 0u);
   if (n_probe) st->rays[2] += *n_probe;
   if (clear0) *clear0 = 0;
   if (clear1) *clear1 = 0;

@@ -20,6 +20,7 @@ struct ShadeQueues {
 struct StageArea {
   RayQueue next, shadow, probe;  // o/d/slot arrays of gridDim.x * region_cap entries; count unused
   uint32_t region_cap;           // entries per wavefront region
+  uint32_t shadow_region_cap;    // the same for `shadow` where the path tracer also appends its probe rays to it
 };
 __device__ inline void stage_push(const RayQueue& stage, uint32_t base, uint32_t& n, bool want, int slot, V3 o,
                                   int seed, V3 d, float tmax) {
@@ -66,6 +67,33 @@ __device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li, uint32
   return Li + bp * Ld;
 }
 
+// The BSDF-sampled direct-light term of a probe ray that reaches emitter triangle `prim` at
+// distance t, barycentrics (b1, b2):  weight * fr * Le * |cos| / pdf  (pathtracer.cu:949-983).
+__device__ inline V3 probe_emitter_term(const DevScene& S, int prim, V3 pos, V3 out, float t, float b1, float b2, V3 fr,
+                                        float pdf, float absdot) {
+  V3 y = v3(0, 0, 0);
+  int light = __float_as_int(S.shade[(size_t)prim * kShadeF4 + 6].y);
+  uint32_t type = __float_as_uint(S.shade[(size_t)prim * kShadeF4 + 7].x) & kPrimTypeMask;
+  if (type == 0u && light != -1) {
+    LightRec l;
+    load_light(S, light, l);
+    const float4* sh = S.shade + (size_t)prim * kShadeF4;
+    V3 n = normalize(v3(sh[0]) * (1.f - b1 - b2) + v3(sh[1]) * b1 + v3(sh[2]) * b2);
+    V3 p = pos + t * out;
+    V3 radiance = dot(n, -out) > 0.f ? l.radiance : v3(0, 0, 0);
+    if (!is_black(radiance)) {
+      float pdfA = 1.f / l.area;
+      float choicePdf = S.light_cdf[light + 1] - S.light_cdf[light];
+      float lenSquare = dot(p - pos, p - pos);
+      float costheta = fabsf(dot(n, out));
+      float lPdf = pdfA * lenSquare / (costheta);
+      float weight = power_heuristic(pdf, lPdf * choicePdf);
+      y = weight * fr * radiance * absdot / pdf;
+    }
+  }
+  return y;
+}
+
 // One vertex of Path() (pathtracer.cu:897-1007) for every path whose
 // extension ray has been traced.
 #ifndef CASTER_SHADE_WAVES
@@ -75,6 +103,9 @@ __device__ inline V3 resolve_pending(const PathState& P, int slot, V3 Li, uint32
 #define CASTER_PROBE_CULL 1
 #endif
 constexpr int kProbeCullLights = 8;  // emitter triangles tested directly before a probe ray is sent
+// PROBE_ANY: the probe rays go to the shadow queue as occlusion rays, their terms settled here (see below;
+// the host asks for it where every probe knows its emitter and the batch is small enough to gain).
+template <bool PROBE_ANY>
 __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
   const DevScene& S = L.S;
   const PathState& P = L.P;
@@ -82,6 +113,7 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
   uint32_t r0, r1;
   wave_rounds(count, r0, r1);
   const uint32_t sbase = blockIdx.x * stage.region_cap;
+  const uint32_t sbase_shadow = blockIdx.x * stage.shadow_region_cap;
   uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
   for (uint32_t r = r0; r < r1; ++r) {
     uint32_t idx = r * kWave + threadIdx.x;
@@ -181,6 +213,7 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
                   py = make_float4(0, 0, 0, 0);
                 } else if (S.n_lights <= kProbeCullLights) {
                   float pmaxD = maxcomp(vabs(mo));
+                  float pb1 = 0.f, pb2 = 0.f;
                   for (int li = 0; li < S.n_lights; ++li) {
                     int lprim = __float_as_int(uniform_load4(S.lights + (size_t)li * kLightF4 + 4).w);
                     const float4* rec = S.isect + (size_t)lprim * kIsectF4;
@@ -191,9 +224,18 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
                         (t < ptmax || (t == ptmax && lprim > pseed) || pseed < 0)) {
                       ptmax = t;
                       pseed = lprim;
+                      pb1 = b1; pb2 = b2;
                     }
                   }
                   if (pseed < 0) { want_probe = false; py = make_float4(0, 0, 0, 0); }
+                  else if (PROBE_ANY) {
+                    // The emitter is known, so is the term it gives if nothing hides it: the probe
+                    // becomes an occlusion ray whose hit clears the term (k_trace<true>), and a
+                    // term that is zero anyway (an emitter seen from behind) needs no ray at all.
+                    V3 y = probe_emitter_term(S, pseed, pos, mo, ptmax, pb1, pb2, mfr, mpdf, absdot);
+                    py = f4(y, 0.f);
+                    want_probe = !is_black(y);
+                  }
                 }
               }
 #endif
@@ -238,72 +280,68 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
       P.li_flags[slot] = f4(Li, flags);
     }
     stage_push(stage.next, sbase, n_next, want_next, slot, no, -1, nd, INFINITY);
-    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, -1, sd, stmax);
-    stage_push(stage.probe, sbase, n_probe, want_probe, slot, po, pseed, pd, ptmax);
+    stage_push(stage.shadow, sbase_shadow, n_shadow, want_shadow, slot, so, -1, sd, stmax);
+    // Where every probe ray sets out knowing the nearest emitter on its line (few emitters, no
+    // environment), whether that emitter is the closest hit is a question of occlusion: is there
+    // a primitive in front of it, or at the same distance with a higher index?  Such a probe
+    // joins the shadow rays (any hit, early exit, two launches less per bounce), marked by the
+    // emitter's index where a shadow ray carries -1.
+    if (PROBE_ANY) {
+      stage_push(stage.shadow, sbase_shadow, n_shadow, want_probe, slot, po, pseed, pd, ptmax);
+      n_probe += (uint32_t)__popcll(__ballot(want_probe));
+    } else {
+      stage_push(stage.probe, sbase, n_probe, want_probe, slot, po, pseed, pd, ptmax);
+    }
   }
   __syncthreads();  // the copy below reads what other lanes of this wavefront staged
   stage_flush(stage.next, sbase, n_next, out.next);
-  stage_flush(stage.shadow, sbase, n_shadow, out.shadow);
-  stage_flush(stage.probe, sbase, n_probe, out.probe);
+  stage_flush(stage.shadow, sbase_shadow, n_shadow, out.shadow);
+  if (PROBE_ANY) {
+    // the probe queue stays empty; its length counter keeps the number of probe rays for the statistics
+    n_probe = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_probe);
+    if ((threadIdx.x & 63u) == 0 && n_probe) atomicAdd(out.probe.count, n_probe);
+  } else {
+    stage_flush(stage.probe, sbase, n_probe, out.probe);
+  }
 }
 
 // BSDF-sampled direct light (pathtracer.cu:949-983), after the probe rays have
 // been traced: an emitter hit (or the environment on a miss) contributes
 // weight * fr * Le * |cos| / pdf into the path's pending term.
-__global__ __launch_bounds__(kWave) void k_probe_resolve(LaunchCtx L, RayQueue q) {
+__device__ inline void probe_resolve_one(const LaunchCtx& L, V3 pos, V3 out, Hit h, int slot) {
   const DevScene& S = L.S;
+  bool found = h.prim >= 0;
+  float4 py = L.P.pend_y[slot];
+  V3 fr = v3(py);
+  float pdf = py.w;
+  float absdot = L.P.pend_x[slot].w;
+  V3 y = v3(0, 0, 0);
+  if (found) {
+    // a hit the ray started out with carries no barycentrics: the same test gives them again
+    float t, b1, b2;
+    bool last;
+    if (prim_test(S, h.prim, pos, out, maxcomp(vabs(out)), S.epsilon, INFINITY, t, b1, b2, last)) {
+      h.b1 = b1; h.b2 = b2;
+    }
+    y = probe_emitter_term(S, h.prim, pos, out, h.t, h.b1, h.b2, fr, pdf, absdot);
+  } else if (S.inf.valid) {
+    V3 radiance = inf_le(S.inf, out);
+    float choicePdf = S.light_cdf[S.n_lights + 1] - S.light_cdf[S.n_lights];
+    float lightPdf = ONE_OVER_FOUR_PI;
+    float weight = power_heuristic(pdf, lightPdf * choicePdf);
+    y = weight * fr * radiance * absdot / pdf;
+  }
+  L.P.pend_y[slot] = f4(y, 0.f);
+}
+__global__ __launch_bounds__(kWave) void k_probe_resolve(LaunchCtx L, RayQueue q) {
   const uint32_t count = *q.count;
   for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < count; idx += gridDim.x * kWave) {
     float4 o4 = q.o[idx], d4 = q.d[idx], h4 = q.hit[idx];
-    int slot = q.slot[idx];
-    V3 pos = v3(o4), out = v3(d4);
     Hit h;
     h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
-    bool found = h.prim >= 0;
-    float4 py = L.P.pend_y[slot];
-    V3 fr = v3(py);
-    float pdf = py.w;
-    float absdot = L.P.pend_x[slot].w;
-    V3 y = v3(0, 0, 0);
-    if (found) {
-      int light = __float_as_int(S.shade[(size_t)h.prim * kShadeF4 + 6].y);
-      uint32_t type = __float_as_uint(S.shade[(size_t)h.prim * kShadeF4 + 7].x) & kPrimTypeMask;
-      if (type == 0u && light != -1) {
-        LightRec l;
-        load_light(S, light, l);
-        // a hit the ray started out with carries no barycentrics: the same test gives them again
-        {
-          float t, b1, b2;
-          bool last;
-          if (prim_test(S, h.prim, pos, out, maxcomp(vabs(out)), S.epsilon, INFINITY, t, b1, b2, last)) {
-            h.b1 = b1; h.b2 = b2;
-          }
-        }
-        const float4* sh = S.shade + (size_t)h.prim * kShadeF4;
-        V3 n = normalize(v3(sh[0]) * (1.f - h.b1 - h.b2) + v3(sh[1]) * h.b1 + v3(sh[2]) * h.b2);
-        V3 p = pos + h.t * out;
-        V3 radiance = dot(n, -out) > 0.f ? l.radiance : v3(0, 0, 0);
-        if (!is_black(radiance)) {
-          float pdfA = 1.f / l.area;
-          float choicePdf = S.light_cdf[light + 1] - S.light_cdf[light];
-          float lenSquare = dot(p - pos, p - pos);
-          float costheta = fabsf(dot(n, out));
-          float lPdf = pdfA * lenSquare / (costheta);
-          float weight = power_heuristic(pdf, lPdf * choicePdf);
-          y = weight * fr * radiance * absdot / pdf;
-        }
-      }
-    } else if (S.inf.valid) {
-      V3 radiance = inf_le(S.inf, out);
-      float choicePdf = S.light_cdf[S.n_lights + 1] - S.light_cdf[S.n_lights];
-      float lightPdf = ONE_OVER_FOUR_PI;
-      float weight = power_heuristic(pdf, lightPdf * choicePdf);
-      y = weight * fr * radiance * absdot / pdf;
-    }
-    L.P.pend_y[slot] = f4(y, 0.f);
+    probe_resolve_one(L, v3(o4), v3(d4), h, q.slot[idx]);
   }
 }
-
 // A vertex whose probe ray was never issued does not set kFPendingY, so its
 // pend_y is not read; issued ones are always overwritten by k_probe_resolve.
 

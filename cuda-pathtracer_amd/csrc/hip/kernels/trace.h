@@ -160,9 +160,15 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       if (ANY) {
         if (occluded) {
           int slot = q.slot[idx];
-          float4 px = L.P.pend_x[slot];
-          px.x = 0.f; px.y = 0.f; px.z = 0.f;
-          L.P.pend_x[slot] = px;
+          if (hit.prim < 0) {
+            float4 px = L.P.pend_x[slot];
+            px.x = 0.f; px.y = 0.f; px.z = 0.f;
+            L.P.pend_x[slot] = px;
+          } else {
+            // a probe ray among the shadow rays: something lies in front of the emitter it was
+            // sent to, and the BSDF-sampled term the vertex stored for that emitter is void
+            L.P.pend_y[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
         }
       } else {
         q.hit[idx] = make_float4(hit.t, __int_as_float(hit.prim), hit.b1, hit.b2);
@@ -260,13 +266,15 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
         bool last;
         bool found = prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last);
         if (found) {
+          // (an occlusion ray holds -1 in hit.prim, or the emitter a probe ray was sent to, at
+          // distance hit.t: the emitter itself and what it hides at equal distance do not occlude)
           if (ANY) {
-            occluded = true;
+            if (t < hit.t || i > hit.prim) occluded = true;
           } else if (t < hit.t || i > hit.prim) {
             hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2;
           }
         }
-        if (ANY && found) {
+        if (ANY && occluded) {
           cur = kRefEmpty;
           pend = kRefEmpty;
         } else {
@@ -289,12 +297,12 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
         bool found = prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last);
         if (found) {
           if (ANY) {
-            occluded = true;
+            if (t < hit.t || i > hit.prim) occluded = true;
           } else if (t < hit.t || i > hit.prim) {
             hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2;
           }
         }
-        if (ANY && found) cur = kRefEmpty;
+        if (ANY && occluded) cur = kRefEmpty;
         else cur = last ? stack_next(st, lane, hit.t) : ~(i + 1);
       }
 #endif

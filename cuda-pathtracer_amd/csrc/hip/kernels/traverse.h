@@ -23,7 +23,7 @@ __device__ inline bool box_test(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float sc
                                __builtin_fmaxf(tzNear, tzFar));
   tFar *= scale;
   tn = tNear;
-  return !(tFar <= 0.00001f) && !(tNear > tFar) && !(tNear > tmax);
+  return !(tFar <= 0.00001f) && !(tNear > tFar) && !(tNear > tmax * fps::kNearCullSlack);
 }
 
 struct Hit {

@@ -298,6 +298,7 @@ struct caster_renderer {
   int shade_grid = 0;
   int bdpt_grid = 0;  // workgroups of k_bdpt (one sample per lane at a time)
   bool lt_queues = false;   // light tracing with its connection rays on queues (no density grid in the scene)
+  bool probe_any = false;   // path tracer: probe rays ride the shadow queue as occlusion rays (few emitters, no environment)
   bool vpt_queues = false;  // volumetric integrator with its shadow and probe rays on queues (no density grid in the scene)
   float* acc = nullptr;
   float* film_tmp = nullptr;
@@ -338,6 +339,9 @@ static int dev_upload(caster_renderer* r, const T** out, const std::vector<T>& v
   return CASTER_OK;
 }
 
+#ifndef CASTER_PROBE_ANY_MAX_SLOTS
+#define CASTER_PROBE_ANY_MAX_SLOTS (40u << 20)  // path slots in flight up to which probe rays ride the shadow queue (1080p: 19 iterations)
+#endif
 static int alloc_queue(caster_renderer* r, RayQueue& q, uint32_t n, bool with_hit, uint32_t* counter) {
   int rc;
   if ((rc = dev_alloc(r, &q.o, n))) return rc;
@@ -364,8 +368,9 @@ static int alloc_lane(caster_renderer* r, Lane& ln) {
   HIPCHECK(hipMemset(ln.counters, 0, (64 + 3 * kWorkShards * kWorkPad) * sizeof(uint32_t)));
   if ((rc = alloc_queue(r, ln.ext[0], n, true, ln.counters + 0))) return rc;
   if ((rc = alloc_queue(r, ln.ext[1], n, true, ln.counters + 1))) return rc;
-  if ((rc = alloc_queue(r, ln.shadow, n, r->vpt_queues || r->lt_queues, ln.counters + 2))) return rc;
-  if ((rc = alloc_queue(r, ln.probe, n, true, ln.counters + 3))) return rc;
+  // (with the probe rays among the shadow rays a path can append two entries to that queue, none to the other)
+  if ((rc = alloc_queue(r, ln.shadow, r->probe_any ? 2 * n : n, r->vpt_queues || r->lt_queues, ln.counters + 2))) return rc;
+  if ((rc = alloc_queue(r, ln.probe, r->probe_any ? kWave : n, true, ln.counters + 3))) return rc;
   if (r->vpt_queues || r->lt_queues) {
     if ((rc = alloc_queue(r, ln.tr1, n, true, ln.counters + 4))) return rc;
     if ((rc = dev_alloc(r, &ln.P.pend_z, n))) return rc;
@@ -376,10 +381,11 @@ static int alloc_lane(caster_renderer* r, Lane& ln) {
   uint32_t rounds = (n + kWave - 1) / kWave;
   uint32_t per = (rounds + (uint32_t)r->shade_grid - 1) / (uint32_t)r->shade_grid;
   ln.stage.region_cap = per * kWave;
+  ln.stage.shadow_region_cap = r->probe_any ? 2 * ln.stage.region_cap : ln.stage.region_cap;
   uint32_t cap = ln.stage.region_cap * (uint32_t)r->shade_grid;
   if ((rc = alloc_queue(r, ln.stage.next, cap, false, nullptr))) return rc;
-  if ((rc = alloc_queue(r, ln.stage.shadow, cap, false, nullptr))) return rc;
-  if ((rc = alloc_queue(r, ln.stage.probe, cap, false, nullptr))) return rc;
+  if ((rc = alloc_queue(r, ln.stage.shadow, ln.stage.shadow_region_cap * (uint32_t)r->shade_grid, false, nullptr))) return rc;
+  if ((rc = alloc_queue(r, ln.stage.probe, r->probe_any ? kWave : cap, false, nullptr))) return rc;
   ln.aux.spill_stride = (uint32_t)r->walk_grid * kWave;
   if ((rc = dev_alloc(r, &ln.aux.spill, (size_t)ln.aux.spill_stride * kSpillDepth))) return rc;
   ln.aux.work = ln.counters + 64;
@@ -483,6 +489,13 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   {
     int per_cu = 8;
     r->vpt_queues = sc.integrator == IT_VPT && !sc.has_heterogeneous;
+    // Every probe ray of the path tracer then starts out with the nearest emitter on its line, and can be
+    // settled in k_shade_pt<true> but for its visibility (see there): two launches less per bounce, for a
+    // heavier shade kernel.  Against a closest-hit probe queue with a resolve kernel of its own, 1080p on
+    // 1.37 M triangles: +19 % with one iteration in flight (678 -> 804 Msamples/s), +7 % with four, +3 %
+    // with sixteen, 1.5 % slower with sixty-four: small batches take it, large ones keep the probe queue.
+    r->probe_any = CASTER_PROBE_CULL && sc.integrator == IT_PT && !sc.infinite.valid &&
+                   (int)sc.lights.size() <= kProbeCullLights && (uint64_t)r->pool_slots <= (uint64_t)CASTER_PROBE_ANY_MAX_SLOTS;
     // light tracing sends its connection rays through the traversal kernel unless a medium is a
     // density grid (its transmittance draws random numbers) -- or the scene is a handful of
     // primitives without media, where walking a three-level tree in place beats three more
@@ -491,7 +504,7 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     const void* fn = sc.integrator == IT_AO ? (const void*)k_shade_ao
                      : sc.integrator == IT_VPT ? (r->vpt_queues ? (const void*)k_shade_vptq : (const void*)k_shade_vpt)
                      : sc.integrator == IT_LT ? (r->lt_queues ? (const void*)k_shade_lt<true> : (const void*)k_shade_lt<false>)
-                                              : (const void*)k_shade_pt;
+                                              : (const void*)k_shade_pt<false>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 8;
     if (per_cu > 20) per_cu = 20;  // the vpt shade stage indexes the spill area sized for 20 wavefronts per CU
     r->shade_grid = r->n_cu * per_cu;
@@ -602,7 +615,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
     // paths' first vertices; both are empty at the end of every round)
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, ln.ext[1].count, r->lt_queues ? (uint32_t*)nullptr : ln.shadow.count,
-                       r->lt_queues ? (uint32_t*)nullptr : ln.probe.count, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init);
+                       r->lt_queues ? (uint32_t*)nullptr : ln.probe.count, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init, 0u);
   }
   const uint32_t live_rays = (uint32_t)S.width * (uint32_t)(r->y1 - r->y0) * n;
   bool failed = false;
@@ -625,7 +638,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
       hipLaunchKernelGGL(k_add_stat, dim3(1), dim3(1), 0, st, ln.stats, 3, (const uint32_t*)tq[tcur]->count);
       hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
-                         ln.counters + 64 + 1 * kWorkShards * kWorkPad, (uint32_t)kWorkShards, r->work_init);
+                         ln.counters + 64 + 1 * kWorkShards * kWorkPad, (uint32_t)kWorkShards, r->work_init, 0u);
       {
         ScopedTimer t(r, st, CASTER_K_SHADOW);
         hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, *tq[tcur], aux_for(1));
@@ -643,7 +656,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
     hipLaunchKernelGGL(k_probe_resolve_vpt, dim3(shade_grid), dim3(kWave), 0, st, L, ln.probe);
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)q.count, (const uint32_t*)nullptr,
                        (const uint32_t*)ln.probe.count, q.count, tq[tcur]->count, ln.probe.count, b == 0 ? live_rays : 0u,
-                       ln.counters + 64, 3u * kWorkShards, r->work_init);
+                       ln.counters + 64, 3u * kWorkShards, r->work_init, 0u);
     cur ^= 1;
   };
   // Light tracing on queues: the connection rays of one round, advanced a Tr() segment per
@@ -655,7 +668,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
       hipLaunchKernelGGL(k_add_stat, dim3(1), dim3(1), 0, st, ln.stats, 3, (const uint32_t*)tq[tcur]->count);
       hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
-                         ln.counters + 64 + 1 * kWorkShards * kWorkPad, (uint32_t)kWorkShards, r->work_init);
+                         ln.counters + 64 + 1 * kWorkShards * kWorkPad, (uint32_t)kWorkShards, r->work_init, 0u);
       {
         ScopedTimer t(r, st, CASTER_K_SHADOW);
         hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, *tq[tcur], aux_for(1));
@@ -689,14 +702,15 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
       else if (S.integrator == IT_LT)
         if (r->lt_queues) hipLaunchKernelGGL(k_shade_lt<true>, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage, ln.aux, r->acc);
         else hipLaunchKernelGGL(k_shade_lt<false>, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage, ln.aux, r->acc);
-      else hipLaunchKernelGGL(k_shade_pt, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
+      else if (r->probe_any) hipLaunchKernelGGL(k_shade_pt<true>, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
+      else hipLaunchKernelGGL(k_shade_pt<false>, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
     }
     if (S.integrator != IT_VPT && S.integrator != IT_LT) {
       {
         ScopedTimer t(r, st, CASTER_K_SHADOW);
         hipLaunchKernelGGL(k_trace<true>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.shadow, aux_for(1));
       }
-      if (S.integrator == IT_PT) {
+      if (S.integrator == IT_PT && !r->probe_any) {   // (else the probe rays were among the shadow rays, their terms settled)
         {
           ScopedTimer t(r, st, CASTER_K_PROBE);
           hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.probe, aux_for(2));
@@ -710,7 +724,8 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)q.count,
                        r->lt_queues ? (const uint32_t*)nullptr : (const uint32_t*)ln.shadow.count,
                        r->lt_queues ? (const uint32_t*)nullptr : (const uint32_t*)ln.probe.count, q.count, ln.shadow.count,
-                       ln.probe.count, b == 0 ? live_rays : 0u, ln.counters + 64, 3u * kWorkShards, r->work_init);
+                       ln.probe.count, b == 0 ? live_rays : 0u, ln.counters + 64, 3u * kWorkShards, r->work_init,
+                       r->probe_any ? 1u : 0u);
     cur ^= 1;
   };
   if (!tail) {
@@ -1009,7 +1024,7 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   auto reset_work = [&]() {
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init);
+                       (uint32_t*)nullptr, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init, 0u);
   };
   reset_work();
   hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.ext[0], ln.aux);

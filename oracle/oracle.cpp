@@ -220,7 +220,7 @@ inline bool BoxIntersect(const Ctx& cx, const Node& nd, const Ray& r) {
   tFar *= 1 + 2 * cx.g3;
   if (tFar <= 0.00001f) return false;
   if (tNear > tFar) return false;
-  if (tNear > r.tmax) return false;
+  if (tNear > r.tmax * fps::kNearCullSlack) return false;  // (bbox.h:96 compares with tmax itself: see fpspec.h)
   return true;
 }
 
