@@ -261,7 +261,9 @@ def main():
         # The dominant kernel is the one with the largest total time in the timed region.  With
         # several streams a launch shares the GPU with the other streams' kernels while it runs, so
         # `exclusive` repeats the measurement on one stream (same batch size), after the timed region.
-        shade_name = {0: "k_shade_ao", 1: "k_shade_pt", 2: "k_shade_vpt", 3: "k_shade_lt", 4: "k_bdpt"}[scene.integrator]
+        shade_name = {0: "k_shade_ao", 1: "k_shade_pt<false>", 2: "k_shade_vpt", 3: "k_shade_lt", 4: "k_bdpt"}[scene.integrator]
+        if scene.integrator == 1 and kt["probe"][1] == 0:
+            shade_name = "k_shade_pt<true>"   # small batches: the probe rays were among the shadow rays, no probe launches
         symbols = {"k_trace<false>": (("extend", 0), ("probe", 2)), "k_trace<true>": (("shadow", 1),),
                    shade_name: (("shade", None),)}
 

@@ -179,7 +179,7 @@ __device__ inline int stack_next(Stack& s, uint32_t lane, float tmax) {
     uint2 e;
     if (s.sp < kLdsDepth) e = lds_get(s, s.sp, lane);
     else e = s.spill[(size_t)(s.sp - kLdsDepth) * s.stride];
-    if (!(__uint_as_float(e.y) > tmax)) return (int)e.x;
+    if (!(__uint_as_float(e.y) > tmax * fps::kNearCullSlack)) return (int)e.x;  // the slab test's own cull, with the ray's present tmax
   }
   return kRefEmpty;
 }

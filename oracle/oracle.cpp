@@ -26,7 +26,11 @@
 //     (pathtracer.cu:181-190 falls off the end); a scene without lights draws
 //     the light-sampling numbers and gets zero radiance;
 //   * at most kMaxCrossings index-matched boundary crossings per path and
-//     per transmittance ray.
+//     per transmittance ray;
+//   * the slab test drops a box entered beyond tmax * (1 + 2^-16), not beyond
+//     tmax itself (bbox.h:96): of two triangles sharing the edge a ray hits
+//     both are then always tested and the closest hit (smallest t, then
+//     highest index) does not depend on the order the tree is walked in.
 #include "oracle.h"
 
 #include <algorithm>
