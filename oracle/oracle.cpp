@@ -374,8 +374,56 @@ inline bool PrimIntersect(const Ctx& cx, int i, Ray& ray, Isect* isect, Counters
   return SphereIntersect(p, i, ray, isect);
 }
 
+// Test aid (oracle_debug_bruteforce): every ray is also tested against all primitives, and a walk
+// of the tree that finds another answer is reported on stderr.
+static bool g_debug_brute = false;
+static void DebugBrute(const Ctx& cx, const Ray& ray0, bool any, bool got, int got_prim, float got_t, int kind) {
+  Counters scratch;
+  Ray r = ray0;
+  Isect is;
+  bool hit = false;
+  for (int i = 0; i < (int)cx.scene.prims.size(); ++i)
+    if (PrimIntersect(cx, i, r, any ? nullptr : &is, scratch, kind)) { hit = true; if (any) break; }
+  if (hit != got || (!any && hit && is.prim != got_prim))
+    fprintf(stderr, "oracle: %s ray kind %d o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) tmax=%.9g: tree %d (prim %d t %.9g), all primitives %d (prim %d t %.9g)\n",
+            any ? "any-hit" : "closest-hit", kind, ray0.origin.x, ray0.origin.y, ray0.origin.z, ray0.dir.x, ray0.dir.y, ray0.dir.z,
+            ray0.tmax, (int)got, got_prim, got_t, (int)hit, any ? -1 : is.prim, any ? 0.f : r.tmax);
+  if (hit != got || (!any && hit && is.prim != got_prim)) {
+    // the chain of boxes above the primitive the walk did not reach, each with its slab test
+    int want = any ? -1 : is.prim;
+    if (want < 0) return;
+    for (size_t n = 0; n < cx.scene.nodes.size(); ++n) {
+      const Node& nd = cx.scene.nodes[n];
+      if (nd.leaf && nd.start <= want && want <= nd.end) {
+        const Prim& pr = cx.scene.prims[want];
+        fprintf(stderr, "  primitive %d is in leaf %zu [%d..%d] box (%.9g %.9g %.9g)-(%.9g %.9g %.9g); vertices (%.9g %.9g %.9g) (%.9g %.9g %.9g) (%.9g %.9g %.9g)\n",
+                want, n, nd.start, nd.end, nd.lo.x, nd.lo.y, nd.lo.z, nd.hi.x, nd.hi.y, nd.hi.z, pr.v[0].v.x, pr.v[0].v.y, pr.v[0].v.z,
+                pr.v[1].v.x, pr.v[1].v.y, pr.v[1].v.z, pr.v[2].v.x, pr.v[2].v.y, pr.v[2].v.z);
+      }
+    }
+    int idx = 0;
+    for (;;) {
+      const Node& nd = cx.scene.nodes[idx];
+      Ray rr = ray0;
+      V3 inv = {1.f / rr.dir.x, 1.f / rr.dir.y, 1.f / rr.dir.z};
+      float tx0 = (nd.lo.x - rr.origin.x) * inv.x, tx1 = (nd.hi.x - rr.origin.x) * inv.x;
+      float ty0 = (nd.lo.y - rr.origin.y) * inv.y, ty1 = (nd.hi.y - rr.origin.y) * inv.y;
+      float tz0 = (nd.lo.z - rr.origin.z) * inv.z, tz1 = (nd.hi.z - rr.origin.z) * inv.z;
+      fprintf(stderr, "  node %d leaf %d box (%.9g %.9g %.9g)-(%.9g %.9g %.9g): x [%.9g %.9g] y [%.9g %.9g] z [%.9g %.9g] -> %d\n", idx, (int)nd.leaf,
+              nd.lo.x, nd.lo.y, nd.lo.z, nd.hi.x, nd.hi.y, nd.hi.z, tx0, tx1, ty0, ty1, tz0, tz1, (int)BoxIntersect(cx, nd, rr));
+      if (nd.leaf) break;
+      // pre-order layout: the first child follows its parent, the second starts at nd.second
+      // and holds the primitives from its first leaf on
+      int probe = nd.second;
+      while (!cx.scene.nodes[probe].leaf) probe = probe + 1;
+      idx = want >= cx.scene.nodes[probe].start ? nd.second : idx + 1;
+    }
+  }
+}
+
 // pathtracer.cu:223-264 (closest hit; unordered depth-first walk)
 bool Intersect(const Ctx& cx, Ray& ray, Isect* isect, Counters& k, int kind) {
+  const Ray ray0 = ray;
   k.c.rays[kind]++;
   if (cx.scene.nodes.empty()) return false;
   std::vector<int>& stack = *([]() { static thread_local std::vector<int> s(256); return &s; })();
@@ -399,11 +447,20 @@ bool Intersect(const Ctx& cx, Ray& ray, Isect* isect, Counters& k, int kind) {
     node_idx = stack[--top];
   }
   if (ret) k.c.hits[kind]++;
+  if (g_debug_brute) DebugBrute(cx, ray0, false, ret, ret && isect ? isect->prim : -1, ray.tmax, kind);
   return ret;
 }
 
 // pathtracer.cu:266-305 (any hit)
+static bool IntersectPrimitiveWalk(const Ctx& cx, Ray& ray, Counters& k, int kind);
 bool IntersectPrimitive(const Ctx& cx, Ray& ray, Counters& k, int kind) {
+  if (!g_debug_brute) return IntersectPrimitiveWalk(cx, ray, k, kind);
+  const Ray ray0 = ray;
+  bool got = IntersectPrimitiveWalk(cx, ray, k, kind);
+  DebugBrute(cx, ray0, true, got, -1, 0.f, kind);
+  return got;
+}
+static bool IntersectPrimitiveWalk(const Ctx& cx, Ray& ray, Counters& k, int kind) {
   k.c.rays[kind]++;
   if (cx.scene.nodes.empty()) return false;
   std::vector<int>& stack = *([]() { static thread_local std::vector<int> s(256); return &s; })();
@@ -2090,6 +2147,8 @@ int oracle_primary_ids_bruteforce(oracle_ctx* c, uint32_t iter, int32_t* ids) {
   }
   return 0;
 }
+
+void oracle_debug_bruteforce(int on) { g_debug_brute = on != 0; }
 
 void oracle_fps(int op, const float* x, const float* y, int n, float* out) {
   for (int i = 0; i < n; ++i) {
