@@ -382,6 +382,9 @@ static void DebugBrute(const Ctx& cx, const Ray& ray0, bool any, bool got, int g
   Ray r = ray0;
   Isect is;
   bool hit = false;
+  float len2 = dot(ray0.dir, ray0.dir);
+  if (!(len2 > 0.999f && len2 < 1.001f))
+    fprintf(stderr, "oracle: ray kind %d has a direction of length^2 %.9g\n", kind, len2);
   for (int i = 0; i < (int)cx.scene.prims.size(); ++i)
     if (PrimIntersect(cx, i, r, any ? nullptr : &is, scratch, kind)) { hit = true; if (any) break; }
   if (hit != got || (!any && hit && is.prim != got_prim))
