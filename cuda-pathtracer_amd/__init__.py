@@ -60,7 +60,7 @@ EXPORTS = [
     "caster_scene_load", "caster_scene_load_device", "caster_scene_get_bvh", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams",
     "caster_set_rows",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
-    "caster_film_add_device", "caster_primary_ids", "caster_get_stats", "caster_reset_stats",
+    "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_get_stats", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
     "caster_write_image", "caster_save_image", "caster_iters_in_flight",
 ]
@@ -114,6 +114,8 @@ def lib():
         L.caster_write_image.argtypes = [C.c_char_p, C.c_int, C.c_int, fp]
         L.caster_save_image.argtypes = [vp, C.c_char_p, C.c_int]
         L.caster_primary_ids.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32)]
+        L.caster_trace_rays.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.caster_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.caster_reset_stats.argtypes = [vp]
         L.caster_set_profiling.argtypes = [vp, C.c_int]
@@ -216,6 +218,18 @@ class Renderer:
         ids = np.empty((self.height, self.width), np.int32)
         _check(lib().caster_primary_ids(self._h, it, ids.ctypes.data_as(C.POINTER(C.c_int32))))
         return ids
+
+    def trace_rays(self, origins, dirs, tmax):
+        """Closest hits (primitive ids, distances) of the caller's rays: (n, 3), (n, 3), (n,) float32."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        tm = np.ascontiguousarray(tmax, np.float32).reshape(-1)
+        n = len(tm)
+        prim = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        _check(lib().caster_trace_rays(self._h, n, fp(o), fp(d), fp(tm), prim.ctypes.data_as(C.POINTER(C.c_int32)), fp(t)))
+        return prim, t
 
     def stats(self):
         st = Stats()

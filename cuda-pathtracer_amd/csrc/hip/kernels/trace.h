@@ -220,8 +220,11 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
           hit.t = d4.w; hit.prim = __float_as_int(o4.w); hit.b1 = hit.b2 = 0.f;
           occluded = false;
           st.sp = 0;
-          // tmax < 0 marks a camera slot outside the image: nothing to trace
-          cur = (d4.w >= 0.f && S.n_nodes) ? 0 : kRefEmpty;
+          // tmax < 0 marks a camera slot outside the image: nothing to trace.  (A tmax that is not
+          // a number -- a light sample at the vertex itself -- bounds nothing: every comparison with
+          // it fails, in the slab test and in the primitive tests, and the ray is traced unbounded,
+          // as the reference traces it.)
+          cur = (!(d4.w < 0.f) && S.n_nodes) ? 0 : kRefEmpty;
         }
         chunk_next += give;
       }

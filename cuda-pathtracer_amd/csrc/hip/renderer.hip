@@ -1037,6 +1037,52 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   return CASTER_OK;
 }
 
+int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, const float* dirs, const float* tmax,
+                      int32_t* prim, float* t) {
+  if (!r || !origins || !dirs || !tmax || !prim || !t) return fail(CASTER_ERR_ARG, "caster_trace_rays: null argument");
+  const uint32_t cap = r->S.integrator == IT_BDPT ? (uint32_t)r->S.slots_per_iter : r->pool_slots;
+  if (n > cap) return fail(CASTER_ERR_ARG, "caster_trace_rays: more rays than the renderer has path slots");
+  if (n == 0) return CASTER_OK;
+  HIPCHECK(hipSetDevice(r->device));
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  Lane& ln = r->lanes[0];
+  hipStream_t st = ln.stream;
+  LaunchCtx L = ctx_of(r, ln);
+  std::vector<float4> o(n), d(n), hit(n);
+  std::vector<int> slot(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    int none = -1;
+    float seed;
+    memcpy(&seed, &none, 4);   // no hit known beforehand
+    o[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], seed);
+    d[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tmax[i]);
+    slot[i] = (int)i;
+  }
+  RayQueue& q = ln.ext[0];
+  HIPCHECK(hipMemcpy(q.o, o.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(q.d, d.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(q.slot, slot.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, q.count, n);
+  auto reset_work = [&]() {
+    hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init, 0u);
+  };
+  reset_work();
+  hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, q, ln.aux);
+  reset_work();
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, q.count, 0u);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(st));
+  HIPCHECK(hipMemcpy(hit.data(), q.hit, n * sizeof(float4), hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; ++i) {
+    memcpy(&prim[i], &hit[i].y, 4);
+    t[i] = hit[i].x;
+  }
+  return CASTER_OK;
+}
+
 int caster_get_stats(caster_renderer* r, caster_stats* out) {
   if (!r || !out) return fail(CASTER_ERR_ARG, "caster_get_stats: null argument");
   HIPCHECK(hipSetDevice(r->device));

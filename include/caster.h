@@ -129,6 +129,14 @@ int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t
    order, hit by the camera ray of every pixel for `iter`; -1 on a miss. */
 int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids);
 
+/* Parity hook (no counterpart in the reference): the closest hit of `n` rays of
+   the caller's, traced by the renderer's traversal kernel from the scene's
+   epsilon to tmax[i].  origins and dirs hold n*3 floats; prim[i] receives the
+   primitive id in BVH leaf order or -1, t[i] the distance.  n may not exceed
+   the renderer's path slots (width*height*iterations in flight). */
+int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, const float* dirs, const float* tmax,
+                      int32_t* prim, float* t);
+
 /* Per-kernel-class device time, measured with HIP events recorded on the
    renderer's own streams around every launch of the class's kernel (extend,
    shadow and probe each bracket exactly one traversal launch; with more than

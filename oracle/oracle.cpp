@@ -382,6 +382,8 @@ static void DebugBrute(const Ctx& cx, const Ray& ray0, bool any, bool got, int g
   Ray r = ray0;
   Isect is;
   bool hit = false;
+  fprintf(stderr, "RAY %d %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", kind, ray0.origin.x, ray0.origin.y, ray0.origin.z, ray0.dir.x,
+          ray0.dir.y, ray0.dir.z, ray0.tmax);
   float len2 = dot(ray0.dir, ray0.dir);
   if (!(len2 > 0.999f && len2 < 1.001f))
     fprintf(stderr, "oracle: ray kind %d has a direction of length^2 %.9g\n", kind, len2);

@@ -135,7 +135,9 @@ def test_probe_rays_as_occlusion_rays_or_on_their_own_queue(caster, tmp_path):
     r.close()
     np.testing.assert_array_equal(again, out[24][0])
     o = ol.Oracle(path)
-    for y in (168, 356):
+    # (scanline 537 holds a shadow ray whose tmax is not a number -- a light sample at the vertex itself --
+    # which bounds nothing and is traced as such)
+    for y in (168, 356, 537):
         np.testing.assert_array_equal(out[24][0][y], o.render(1, 24, 8, rows=(y, y + 1))[y])
     assert out[2][1]["rays"][0] == out[24][1]["rays"][0] and out[2][1]["rays"][1] == out[24][1]["rays"][1]
     # a probe whose term is zero anyway (an emitter seen from behind) is not sent as an occlusion ray

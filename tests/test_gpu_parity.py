@@ -57,3 +57,37 @@ def test_film_matches_oracle(caster, scenes, key):
     print(key, "relRMSE %.3g, pixels differing %.4f%%, exact-equal %s" % (err, 100 * frac, np.array_equal(gpu, cpu)))
     assert err <= 1e-3
     assert frac <= 0.002
+
+
+def test_traversal_kernel_against_oracle_ray_by_ray(caster, scenes):
+    """caster_trace_rays (the renderer's traversal kernel on rays of the caller's) returns the oracle's
+    closest hit -- same primitive, same distance to the bit -- for rays from all over the staircase,
+    bounded and unbounded, of unit and other lengths, and for a tmax that is not a number (which bounds
+    nothing: every comparison with it fails)."""
+    import ctypes as C
+    sc = caster.Scene(scenes["stairs_pt"])
+    o = ol.Oracle(scenes["stairs_pt"])
+    rng = np.random.RandomState(9)
+    n = 6000
+    org = (rng.rand(n, 3) * [6.0, 4.0, 6.0] + [-3.0, 0.2, -3.0]).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::7] *= 1.5                                                    # not every direction the integrators make is a unit vector
+    d = d.astype(np.float32)
+    tmax = np.full(n, np.inf, np.float32)
+    tmax[1::3] = (rng.rand(len(tmax[1::3])) * 4).astype(np.float32)
+    tmax[5::50] = np.nan
+    r = caster.Renderer(sc, 0, 1)
+    prim, t = r.trace_rays(org, d, tmax)
+    r.close()
+    o.L.oracle_trace.restype = C.c_int
+    hits = 0
+    for i in range(n):
+        out = (C.c_float * 12)()
+        p = o.L.oracle_trace(o.h, (C.c_float * 3)(*org[i]), (C.c_float * 3)(*d[i]), C.c_float(sc.info.epsilon), C.c_float(tmax[i]), out)
+        assert p == prim[i], (i, p, prim[i], tmax[i])
+        if p >= 0:
+            hits += 1
+            assert out[0] == t[i], (i, out[0], t[i])
+    assert n // 3 < hits < n
+    assert (prim[5::50] >= 0).sum() > 10                             # the unbounded-by-NaN rays hit things
