@@ -100,6 +100,14 @@ __device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, floa
     else if (t2 > 0.f) th = t2;
     else return false;
     if (th > tmax) return false;
+    // The roots are distances only for a unit direction, and rays that leave a line or a sphere
+    // carry others: a candidate in front of the point where the ray enters the sphere's own
+    // bounding box (c -+ r, the box the tree encloses) is no hit.  What remains lies behind the
+    // entry of every box above it, so it is tested whenever it could still win, whatever the
+    // order the tree is walked in.
+    float tn;
+    (void)box_test(v3(a) - radius, v3(a) + radius, o, v3(1.f / d.x, 1.f / d.y, 1.f / d.z), INFINITY, S.box_scale, tn);
+    if (tn > th * fps::kNearCullSlack) return false;
     t = th; ob1 = 0.f; ob2 = 0.f;
     return true;
   }

@@ -18,6 +18,16 @@
 //   * a sphere hit whose chosen root lies beyond ray.tmax is rejected (the
 //     reference accepts the far root unconditionally, sphere.h:61-66, which
 //     would make the result depend on traversal order);
+//   * a sphere candidate that lies before the point where the ray enters the
+//     sphere's own bounding box is rejected.  sphere.h:24-66 assumes a unit
+//     direction; rays leaving a Line primitive (n = -dir, line.h:74-76) or a
+//     sphere (dpdu not orthogonal to n, sphere.h:74-80) carry directions of
+//     other lengths, the roots are then no distances, and a "hit" reported in
+//     front of the box is found or not depending on whether another hit has
+//     shortened the ray before the sphere's leaf is reached.  With the rule a
+//     candidate at t implies that every box above it is entered at or before
+//     t, so it is tested whenever it could still win: the closest hit is a
+//     function of the ray alone;
 //   * Line hits leave the medium indices at -1 (line.h:74-84 leaves them
 //     uninitialised);
 //   * a non-finite sample contributes nothing and an AO miss is (1,1,1) (the
@@ -208,19 +218,25 @@ struct Counters {
   Counters() { memset(&c, 0, sizeof(c)); }
 };
 
-// bbox.h:75-98
-inline bool BoxIntersect(const Ctx& cx, const Node& nd, const Ray& r) {
+// The two distances of the slab test (bbox.h:76-87): where the ray enters and leaves the box.
+inline void SlabDistances(V3 lo, V3 hi, const Ray& r, float& tNear, float& tFar) {
   V3 inv = {1.f / r.dir.x, 1.f / r.dir.y, 1.f / r.dir.z};
-  float txNear = (nd.lo.x - r.origin.x) * inv.x;
-  float txFar = (nd.hi.x - r.origin.x) * inv.x;
-  float tyNear = (nd.lo.y - r.origin.y) * inv.y;
-  float tyFar = (nd.hi.y - r.origin.y) * inv.y;
-  float tzNear = (nd.lo.z - r.origin.z) * inv.z;
-  float tzFar = (nd.hi.z - r.origin.z) * inv.z;
+  float txNear = (lo.x - r.origin.x) * inv.x;
+  float txFar = (hi.x - r.origin.x) * inv.x;
+  float tyNear = (lo.y - r.origin.y) * inv.y;
+  float tyFar = (hi.y - r.origin.y) * inv.y;
+  float tzNear = (lo.z - r.origin.z) * inv.z;
+  float tzFar = (hi.z - r.origin.z) * inv.z;
   using fps::fmax_;
   using fps::fmin_;
-  float tNear = fmax_(fmax_(fmin_(txNear, txFar), fmin_(tyNear, tyFar)), fmin_(tzNear, tzFar));
-  float tFar = fmin_(fmin_(fmax_(txNear, txFar), fmax_(tyNear, tyFar)), fmax_(tzNear, tzFar));
+  tNear = fmax_(fmax_(fmin_(txNear, txFar), fmin_(tyNear, tyFar)), fmin_(tzNear, tzFar));
+  tFar = fmin_(fmin_(fmax_(txNear, txFar), fmax_(tyNear, tyFar)), fmax_(tzNear, tzFar));
+}
+
+// bbox.h:75-98
+inline bool BoxIntersect(const Ctx& cx, const Node& nd, const Ray& r) {
+  float tNear, tFar;
+  SlabDistances(v3(nd.lo), v3(nd.hi), r, tNear, tFar);
   tFar *= 1 + 2 * cx.g3;
   if (tFar <= 0.00001f) return false;
   if (tNear > tFar) return false;
@@ -308,6 +324,15 @@ inline bool SphereIntersect(const Prim& p, int id, Ray& ray, Isect* isect) {
   else if (t2 > 0.f) th = t2;
   else return false;
   if (th > ray.tmax) return false;  // fixed convention, see file header
+  {
+    // Fixed convention (file header): the roots above are distances only for a unit direction.
+    // A candidate that lies before the point where the ray enters the sphere's own bounding box
+    // (sphere.h:15-18, the box the tree encloses) is no hit.
+    V3 rr = v3(radius, radius, radius);
+    float tNear, tFar;
+    SlabDistances(origin - rr, origin + rr, ray, tNear, tFar);
+    if (tNear > th * fps::kNearCullSlack) return false;
+  }
   ray.tmax = th;
   if (isect) {
     isect->pos = ray.at(ray.tmax);

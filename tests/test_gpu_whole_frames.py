@@ -1,0 +1,56 @@
+"""Whole frames of the benchmark configurations, GPU against the CPU oracle, every pixel equal.
+
+The other full-size tests compare the first-hit map of the whole frame and the film of a band of
+scanlines; these compare the film of the WHOLE frame at a few samples per pixel -- tens of millions of
+samples each, through every material, both light-sampling strategies, lines, spheres and the medium --
+and the ray statistics with it.  The bar is bit equality: the closest hit is a function of the ray
+alone on both sides (smallest distance, then highest primitive index; boxes culled with a slack; a
+sphere candidate in front of its own bounding box rejected), so the order in which a wavefront happens
+to walk the tree cannot show."""
+import time
+
+import numpy as np
+import pytest
+
+import gen_scenes
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+# key -> (generator scene, detail, width, height, maxDepth, samples per pixel)
+FRAMES = {
+    "C3_stairs_1080p": ("stairs_pt", 1.0, 1920, 1080, 8, 16),     # 3.3e7 samples; lines and spheres on the railing
+    "C4_cornell_fog_1024": ("cornell_vpt", 1.0, 1024, 1024, 16, 8),  # 8.4e6 samples; spheres inside the medium
+    "C5_car_1080p": ("car_pt", 1.0, 1920, 1080, 8, 4),             # 8.3e6 samples; 1.37 M primitives
+}
+
+
+@pytest.mark.parametrize("key", sorted(FRAMES))
+def test_whole_frame_equals_oracle(caster, tmp_path, key):
+    name, detail, w, h, depth, spp = FRAMES[key]
+    path = gen_scenes.generate(str(tmp_path / key), name, detail, w, h, depth)
+    sc = caster.Scene(path)
+    r = caster.Renderer(sc, 0, 0)
+    r.render(1, spp, True)
+    gpu = r.read_film(2)
+    st = r.stats()
+    r.close()
+    assert st["stack_overflow"] == 0 and st["samples"] == w * h * spp
+    o = ol.Oracle(path)
+    counts = ol.Counts()
+    cpu = np.zeros_like(gpu)
+    t0 = time.time()
+    band = 120
+    for y0 in range(0, h, band):   # in bands, so that a long run keeps printing
+        y1 = min(y0 + band, h)
+        cpu[y0:y1] = o.render(1, spp, 16, rows=(y0, y1), counts=counts)[y0:y1]
+        print("oracle rows %d of %d after %.0f s" % (y1, h, time.time() - t0), flush=True)
+    bad = np.argwhere((gpu != cpu).any(axis=2))
+    assert len(bad) == 0, "%d pixels differ, first (y, x): %s" % (len(bad), bad[:8].tolist())
+    c = counts.as_dict()
+    print("rays gpu %s oracle %s" % (st["rays"], c["rays"]))
+    assert st["invalid"] == c["invalid"]
+    if sc.integrator == caster.IT_PT:
+        # one extension ray per path vertex on both sides (the GPU sends fewer shadow and probe rays:
+        # it skips those whose term is zero whatever they hit)
+        assert st["rays"][0] == c["rays"][0]
