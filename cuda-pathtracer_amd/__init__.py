@@ -46,6 +46,8 @@ class Stats(C.Structure):
                 "stack_overflow": self.stack_overflow}
 
 
+STATIC_MAX_RAYS = 1 << 18   # CASTER_STATIC_MAX_RAYS of include/caster.h
+
 KERNEL_CLASSES = ["generate", "extend", "shade", "shadow", "probe", "finish"]
 
 
@@ -60,7 +62,7 @@ EXPORTS = [
     "caster_scene_load", "caster_scene_load_device", "caster_scene_get_bvh", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams",
     "caster_set_rows",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
-    "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_get_stats", "caster_reset_stats",
+    "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_trace_rays_static", "caster_get_stats", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
     "caster_write_image", "caster_save_image", "caster_iters_in_flight",
 ]
@@ -116,6 +118,7 @@ def lib():
         L.caster_primary_ids.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32)]
         L.caster_trace_rays.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+        L.caster_trace_rays_static.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
         L.caster_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.caster_reset_stats.argtypes = [vp]
         L.caster_set_profiling.argtypes = [vp, C.c_int]
@@ -230,6 +233,11 @@ class Renderer:
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         _check(lib().caster_trace_rays(self._h, n, fp(o), fp(d), fp(tm), prim.ctypes.data_as(C.POINTER(C.c_int32)), fp(t)))
         return prim, t
+
+    def trace_rays_static(self, n, origins_ptr, dirs_ptr, tmax_ptr, prim_ptr, t_ptr):
+        """trace_rays on DEVICE arrays of the caller's (addresses), through the entry point that allocates nothing."""
+        _check(lib().caster_trace_rays_static(self._h, int(n), *[C.c_void_p(p) for p in (origins_ptr, dirs_ptr, tmax_ptr,
+                                                                                     prim_ptr, t_ptr)]))
 
     def stats(self):
         st = Stats()

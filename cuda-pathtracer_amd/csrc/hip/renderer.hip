@@ -21,6 +21,18 @@
 #include "../scene/scene.h"
 #include "kernels.hip"
 
+// Scratch of caster_trace_rays_static, the entry point that allocates nothing: the ray queue its
+// kernels work on (origin | known hit, direction | tmax, slot, hit record), the queue length and the
+// traversal kernel's work counters.  One copy per GPU, held until the process ends.  In host code
+// this name is only a handle for hipGetSymbolAddress: the device address of each GPU's copy is
+// looked up once per device (static_scratch_of) and that pointer is what kernels and memsets get.
+namespace caster {
+constexpr uint32_t kStaticMaxRays = CASTER_STATIC_MAX_RAYS;
+constexpr size_t kStaticCounterWords = 64 + 3 * (size_t)kWorkShards * kWorkPad;
+constexpr size_t kStaticScratchBytes = (size_t)kStaticMaxRays * (3 * sizeof(float4) + sizeof(int)) + kStaticCounterWords * sizeof(uint32_t);
+}
+static __device__ __align__(256) unsigned char scratch[caster::kStaticScratchBytes];
+
 namespace caster {
 
 static thread_local std::string g_last_error;
@@ -36,6 +48,22 @@ static int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess)                                                                     \
       return fail(CASTER_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));      \
   } while (0)
+
+// Device address of `scratch` on each GPU (every device holds its own copy at its own address).
+constexpr int kMaxDevices = 64;
+static void* g_static_scratch[kMaxDevices] = {nullptr};
+// Looks the address up on first use for `device`, which must be the current device.
+static int static_scratch_of(int device, void** out) {
+  if (device < 0 || device >= kMaxDevices) return fail(CASTER_ERR_ARG, "device index beyond the static scratch table");
+  if (!g_static_scratch[device]) {
+    void* p = nullptr;
+    HIPCHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(CASTER_ERR_DEVICE, "hipGetSymbolAddress returned no address for the static scratch");
+    g_static_scratch[device] = p;
+  }
+  *out = g_static_scratch[device];
+  return CASTER_OK;
+}
 
 static inline float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 static inline float as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
@@ -303,6 +331,7 @@ struct caster_renderer {
   float* acc = nullptr;
   float* film_tmp = nullptr;
   int32_t* ids = nullptr;
+  void* static_scratch = nullptr;  // this device's copy of `scratch` (caster_trace_rays_static)
   int iters_in_flight = 1;
   uint32_t pool_slots = 0;
   uint32_t iterations = 0;
@@ -404,6 +433,10 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   hipDeviceProp_t prop;
   HIPCHECK(hipGetDeviceProperties(&prop, device_id));
   r->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    int rc_s = static_scratch_of(device_id, &r->static_scratch);
+    if (rc_s) return rc_s;
+  }
 
   HostArrays A;
   build_arrays(sc, A);
@@ -1080,6 +1113,61 @@ int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, cons
     memcpy(&prim[i], &hit[i].y, 4);
     t[i] = hit[i].x;
   }
+  return CASTER_OK;
+}
+
+// caster_trace_rays_static: device-side conversion between the caller's arrays and the queue layout
+__global__ void k_pack_rays(uint32_t n, const float* origins, const float* dirs, const float* tmax, RayQueue q) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    q.o[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], __int_as_float(-1));  // no hit known beforehand
+    q.d[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tmax[i]);
+    q.slot[i] = (int)i;
+  }
+}
+__global__ void k_unpack_hits(uint32_t n, const float4* hit, int32_t* prim, float* t) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 h = hit[i];
+    prim[i] = __float_as_int(h.y);
+    t[i] = h.x;
+  }
+}
+
+int caster_trace_rays_static(caster_renderer* r, uint32_t n, const float* origins_dev, const float* dirs_dev,
+                             const float* tmax_dev, int32_t* prim_dev, float* t_dev) {
+  if (!r || !origins_dev || !dirs_dev || !tmax_dev || !prim_dev || !t_dev)
+    return fail(CASTER_ERR_ARG, "caster_trace_rays_static: null argument");
+  if (n > kStaticMaxRays)
+    return fail(CASTER_ERR_ARG, "caster_trace_rays_static: more than CASTER_STATIC_MAX_RAYS (" + std::to_string(kStaticMaxRays) +
+                                    ") rays in one call");
+  if (n == 0) return CASTER_OK;
+  if (!r->static_scratch) return fail(CASTER_ERR_DEVICE, "caster_trace_rays_static: no static scratch on this device");
+  HIPCHECK(hipSetDevice(r->device));
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  Lane& ln = r->lanes[0];
+  hipStream_t st = ln.stream;
+  LaunchCtx L = ctx_of(r, ln);
+  // the queue and its counters, carved out of this device's copy of the scratch array
+  unsigned char* base = (unsigned char*)r->static_scratch;
+  RayQueue q;
+  q.o = (float4*)base;
+  q.d = q.o + kStaticMaxRays;
+  q.hit = q.d + kStaticMaxRays;
+  q.slot = (int*)(q.hit + kStaticMaxRays);
+  uint32_t* counters = (uint32_t*)(q.slot + kStaticMaxRays);
+  q.count = counters;
+  WalkAux aux = ln.aux;          // (the stack spill columns are the renderer's, allocated by caster_begin)
+  aux.work = counters + 64;
+  // every call on a GPU shares the array, which still holds the previous call's contents: the
+  // queue entries [0, n) are rewritten below, the length and the work counters are set here
+  HIPCHECK(hipMemsetAsync(counters, 0, kStaticCounterWords * sizeof(uint32_t), st));
+  const int grid = (int)std::min<uint32_t>((n + 255) / 256, (uint32_t)r->n_cu * 8);
+  hipLaunchKernelGGL(k_pack_rays, dim3(grid), dim3(256), 0, st, n, origins_dev, dirs_dev, tmax_dev, q);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, q.count, n);
+  hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, q, aux);
+  hipLaunchKernelGGL(k_unpack_hits, dim3(grid), dim3(256), 0, st, n, (const float4*)q.hit, prim_dev, t_dev);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(st));
   return CASTER_OK;
 }
 

@@ -137,6 +137,20 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids);
 int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, const float* dirs, const float* tmax,
                       int32_t* prim, float* t);
 
+/* caster_trace_rays for callers that cannot allocate device memory (code under HIP
+   graph capture, tight serving loops, harnesses that forbid hipMalloc).  No
+   counterpart in the reference.  Every pointer is DEVICE memory on the renderer's
+   GPU, laid out as in caster_trace_rays; the call makes no hipMalloc / hipFree (nor
+   any other allocating call): the ray queue and the work counters its kernels need
+   live in a static device array of CASTER_STATIC_MAX_RAYS * 52 bytes + 6.4 KB
+   (13.6 MB) that every GPU the library runs on holds until the process ends.  n
+   beyond CASTER_STATIC_MAX_RAYS is CASTER_ERR_ARG.  All calls on one GPU share
+   that array: calls that overlap on one GPU (from several threads or renderers)
+   race; consecutive calls do not.  Returns after the GPU has finished. */
+#define CASTER_STATIC_MAX_RAYS (1u << 18)
+int caster_trace_rays_static(caster_renderer* r, uint32_t n, const float* origins_dev, const float* dirs_dev,
+                             const float* tmax_dev, int32_t* prim_dev, float* t_dev);
+
 /* Per-kernel-class device time, measured with HIP events recorded on the
    renderer's own streams around every launch of the class's kernel (extend,
    shadow and probe each bracket exactly one traversal launch; with more than
