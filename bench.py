@@ -88,6 +88,22 @@ def pmc_traffic_per_launch(kernel):
         return None
 
 
+def launch_ranks(n, argv):
+    """Runs this script under torch.distributed.run with `n` ranks on this node (one per GPU) as a
+    child process and returns its exit status; the ranks' output passes through unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,9 +126,17 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses device 0 (rehearsal only)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher: start one rank per GPU ourselves -- before anything here has
+        # touched the GPU -- and pass on rank 0's line and the launcher's exit status.
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d: start it with --nproc-per-node %d, or without a "
+                         "launcher (it then starts its own ranks)" % (a.gpus, world, a.gpus))
     import torch
     dist = None
     dev_index = 0 if a.share_gpu else local_rank
@@ -193,7 +217,10 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Msamples/s bmw-m6 1080p path+MIS",
+            "metric": "Msamples/s %s %s %s" % (
+                STAND_IN.get(a.scene, a.scene).replace(" stand-in", ""),
+                "1080p" if (scene.width, scene.height) == (1920, 1080) else "%dx%d" % (scene.width, scene.height),
+                {1: "path+MIS"}.get(scene.integrator, caster.INTEGRATOR_NAMES[scene.integrator])),
             "value": total_samples / dt / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,

@@ -22,6 +22,7 @@
 #include "kernels/traverse.h"
 #include "kernels/trace.h"
 #include "kernels/shading.h"
+#include "kernels/bsdf.h"
 #include "kernels/path.h"
 #include "kernels/volpath.h"
 #include "kernels/lighttrace.h"

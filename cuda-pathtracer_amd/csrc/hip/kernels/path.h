@@ -1,4 +1,4 @@
-// Part of the gfx950 wavefront renderer (included by ../kernels.hip, in this order: common.h, traverse.h, trace.h, shading.h, path.h, volpath.h, lighttrace.h, bdpt.h, volpath_queues.h, film.h).
+// Part of the gfx950 wavefront renderer (included by ../kernels.hip, in this order: common.h, traverse.h, trace.h, shading.h, bsdf.h, path.h, volpath.h, lighttrace.h, bdpt.h, volpath_queues.h, film.h).
 // Queue staging, the path-tracing vertex (k_shade_pt), its probe resolution, the AO vertex.
 #pragma once
 
@@ -99,209 +99,288 @@ __device__ inline V3 probe_emitter_term(const DevScene& S, int prim, V3 pos, V3 
 #ifndef CASTER_SHADE_WAVES
 #define CASTER_SHADE_WAVES 4
 #endif
+#ifndef CASTER_SHADE_CHUNK
+#define CASTER_SHADE_CHUNK 8   // rounds (of 64 queue entries) per chunk; chunks are dealt to the shade wavefronts round-robin
+#endif
+#ifndef CASTER_SHADE_SORT
+#define CASTER_SHADE_SORT 0    // 1: vertices are shaded in groups of one material type; 0: in groups of hits of any type
+#endif
 #ifndef CASTER_PROBE_CULL
 #define CASTER_PROBE_CULL 1
 #endif
 constexpr int kProbeCullLights = 8;  // emitter triangles tested directly before a probe ray is sent
+
+// Where the rays a shading wavefront emits go: its staging regions and how full they are.
+struct StageCursor {
+  uint32_t base, base_shadow;
+  uint32_t n_next, n_shadow, n_probe;
+};
+
+// The vertices at queue entries `idx` of the lanes with `active` set, one per lane.
 // PROBE_ANY: the probe rays go to the shadow queue as occlusion rays, their terms settled here (see below;
 // the host asks for it where every probe knows its emitter and the batch is small enough to gain).
 template <bool PROBE_ANY>
-__global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
+__device__ inline void shade_pt_vertices(const LaunchCtx& L, const RayQueue& cur, const StageArea& stage, StageCursor& sc,
+                                         uint32_t idx, bool active) {
   const DevScene& S = L.S;
   const PathState& P = L.P;
-  const uint32_t count = *cur.count;
-  uint32_t r0, r1;
-  wave_rounds(count, r0, r1);
-  const uint32_t sbase = blockIdx.x * stage.region_cap;
-  const uint32_t sbase_shadow = blockIdx.x * stage.shadow_region_cap;
-  uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
-  for (uint32_t r = r0; r < r1; ++r) {
-    uint32_t idx = r * kWave + threadIdx.x;
-    bool active = idx < count;
-    int slot = 0;
-    bool want_next = false, want_shadow = false, want_probe = false;
-    V3 no = v3(0, 0, 0), nd = v3(0, 0, 1), so = no, sd = nd, po = no, pd = nd;
-    float stmax = 0.f, ptmax = INFINITY;
-    int pseed = -1;
-    if (active) {
-      slot = cur.slot[idx];
-      float4 d4 = cur.d[idx], h4 = cur.hit[idx];
-      active = d4.w >= 0.f || __float_as_int(h4.y) >= 0;  // else a slot outside the image: it never contributes
+  int slot = 0;
+  bool want_next = false, want_shadow = false, want_probe = false;
+  V3 no = v3(0, 0, 0), nd = v3(0, 0, 1), so = no, sd = nd, po = no, pd = nd;
+  float stmax = 0.f, ptmax = INFINITY;
+  int pseed = -1;
+  if (active) {
+    slot = cur.slot[idx];
+    float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+    V3 ro = v3(o4), rd = v3(d4);
+    Hit h;
+    h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+    float4 br = P.beta_rng[slot], lf = P.li_flags[slot];
+    V3 beta = v3(br), Li = v3(lf);
+    uint32_t rng = __float_as_uint(br.w), flags = __float_as_uint(lf.w);
+    int bounces = (int)(flags & kFBounceMask);
+    bool specular = (flags & kFSpecular) != 0;
+    if (flags & kFPending) {
+      Li = resolve_pending(P, slot, Li, flags);
+      flags &= ~(kFPending | kFPendingY);
     }
-    if (active) {
-      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
-      V3 ro = v3(o4), rd = v3(d4);
-      Hit h;
-      h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
-      float4 br = P.beta_rng[slot], lf = P.li_flags[slot];
-      V3 beta = v3(br), Li = v3(lf);
-      uint32_t rng = __float_as_uint(br.w), flags = __float_as_uint(lf.w);
-      int bounces = (int)(flags & kFBounceMask);
-      bool specular = (flags & kFSpecular) != 0;
-      if (flags & kFPending) {
-        Li = resolve_pending(P, slot, Li, flags);
-        flags &= ~(kFPending | kFPendingY);
-      }
-      bool alive = true;
-      if (h.prim < 0) {
-        if ((bounces == 0 || specular) && S.inf.valid) Li = Li + beta * inf_le(S.inf, rd);
+    bool alive = true;
+    if (h.prim < 0) {
+      if ((bounces == 0 || specular) && S.inf.valid) Li = Li + beta * inf_le(S.inf, rd);
+      alive = false;
+    }
+    if (alive) {
+      Isect is;
+      load_isect(S, ro, rd, h, is);
+      V3 pos = is.pos, nor = is.n;
+      if ((bounces == 0 || specular) && is.light != -1) {
+        // Area::Le (area.h:36-39)
+        LightRec l;
+        load_light(S, is.light, l);
+        V3 le = dot(nor, -rd) > 0.f ? l.radiance : v3(0, 0, 0);
+        Li = Li + beta * le;
         alive = false;
       }
       if (alive) {
-        Isect is;
-        load_isect(S, ro, rd, h, is);
-        V3 pos = is.pos, nor = is.n, dpdu = is.dpdu;
-        V2 uv = is.uv;
         Mat m;
         load_mat(S, is.mat, m);
-        resolve_texture(S, m, uv);
-        if ((bounces == 0 || specular) && is.light != -1) {
-          // Area::Le (area.h:36-39)
-          LightRec l;
-          load_light(S, is.light, l);
-          V3 le = dot(nor, -rd) > 0.f ? l.radiance : v3(0, 0, 0);
-          Li = Li + beta * le;
-          alive = false;
+        const bool delta = is_delta(m.type);
+        // every random number of the vertex, in the reference's order: light choice and point (3),
+        // light probe (3), continuation (3) -- a specular surface draws the last three only
+        V3 radiance = v3(0, 0, 0), ldir = v3(0, 0, 1), us = v3(0, 0, 0), u;
+        float ltmax = 0.f, lightPdf = 1.f, choicePdf = 1.f;
+        if (!delta) {
+          sample_one_light(S, rng, pos, radiance, ldir, ltmax, lightPdf, choicePdf);
+          us.x = rng_uniform(rng); us.y = rng_uniform(rng); us.z = rng_uniform(rng);
         }
-        if (alive) {
-          if (!is_delta(m.type)) {
-            // light sampling
-            V3 radiance, ldir;
-            float ltmax, lightPdf, choicePdf;
-            sample_one_light(S, rng, pos, radiance, ldir, ltmax, lightPdf, choicePdf);
-            V3 x = v3(0, 0, 0);
-            if (!is_black(radiance)) {
-              V3 fr;
-              float samplePdf;
-              eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
-              float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
-              x = weight * fr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
-              // The reference traces the shadow ray before it evaluates the BSDF
-              // (pathtracer.cu:933-940); when the term is exactly zero (light behind
-              // the surface, zero BSDF) visibility cannot change Ld, so no ray is sent.
-              want_shadow = !is_black(x);
-              so = pos; sd = ldir; stmax = ltmax;
-            }
-            // BSDF sampling for direct light
-            V3 us;
-            us.x = rng_uniform(rng); us.y = rng_uniform(rng); us.z = rng_uniform(rng);
-            V3 mo, mfr;
-            float mpdf;
-            sample_bsdf(S, m, -rd, nor, uv, dpdu, us, mo, mfr, mpdf);
-            float4 py = make_float4(0, 0, 0, 0);
-            float absdot = 0.f;
-            if (!is_black(mfr) && mpdf != 0) {
-              want_probe = true;
-              po = pos; pd = mo;
-              py = f4(mfr, mpdf);
-              absdot = fabsf(dot(mo, nor));
+        u.x = rng_uniform(rng); u.y = rng_uniform(rng); u.z = rng_uniform(rng);
+        // the three questions to the material: the light's direction, a direction of its own
+        // choosing for the light probe, another for the continuation
+        const bool lit = !is_black(radiance);
+        V3 lfr = v3(0, 0, 0), mo = v3(0, 0, 1), mfr = v3(0, 0, 0), wo2 = v3(0, 0, 1), fr2 = v3(0, 0, 0);
+        float lpdf = 0.f, mpdf = 0.f, pdf2 = 0.f;
+        with_lobe(S, m, Surface{-rd, nor, is.dpdu}, is.uv, [&](const auto& lobe) {
+          if (!lobe.kDelta) {
+            if (lit) lobe.eval(ldir, lfr, lpdf);
+            lobe.sample(us, true, mo, mfr, mpdf);
+          }
+          lobe.sample(u, true, wo2, fr2, pdf2);
+        });
+        if (!delta) {
+          V3 x = v3(0, 0, 0);
+          if (lit) {
+            float weight = power_heuristic(lightPdf * choicePdf, lpdf);
+            x = weight * lfr * radiance * fabsf(dot(nor, ldir)) / (lightPdf * choicePdf);
+            // The reference traces the shadow ray before it evaluates the BSDF
+            // (pathtracer.cu:933-940); when the term is exactly zero (light behind
+            // the surface, zero BSDF) visibility cannot change Ld, so no ray is sent.
+            want_shadow = !is_black(x);
+            so = pos; sd = ldir; stmax = ltmax;
+          }
+          float4 py = make_float4(0, 0, 0, 0);
+          float absdot = 0.f;
+          if (!is_black(mfr) && mpdf != 0) {
+            want_probe = true;
+            po = pos; pd = mo;
+            py = f4(mfr, mpdf);
+            absdot = fabsf(dot(mo, nor));
 #if CASTER_PROBE_CULL
-              // The probe only contributes when its closest hit is an emitter (no
-              // environment light here), so a ray that cannot reach one is not
-              // sent.  With few emitters their triangles are tested with the very
-              // test the traversal uses: if none is hit, the closest hit cannot be
-              // one; otherwise the ray starts out holding the nearest emitter hit,
-              // so that the traversal only looks for something at least as close.
-              if (!S.inf.valid) {
-                // first the padded box around all emitters: a ray that misses it cannot hit one
-                float tn;
-                bool reach = S.n_lights > 0 &&
-                             box_test(v3(S.emit_lo), v3(S.emit_hi), pos, v3(1.f / mo.x, 1.f / mo.y, 1.f / mo.z), INFINITY,
-                                      S.box_scale, tn);
-                if (!reach) {
-                  want_probe = false;
-                  py = make_float4(0, 0, 0, 0);
-                } else if (S.n_lights <= kProbeCullLights) {
-                  float pmaxD = maxcomp(vabs(mo));
-                  float pb1 = 0.f, pb2 = 0.f;
-                  for (int li = 0; li < S.n_lights; ++li) {
-                    int lprim = __float_as_int(uniform_load4(S.lights + (size_t)li * kLightF4 + 4).w);
-                    const float4* rec = S.isect + (size_t)lprim * kIsectF4;
-                    float t, b1, b2;
-                    bool last;
-                    if (prim_test_rec(S, uniform_load4(rec), uniform_load4(rec + 1), uniform_load4(rec + 2), pos, mo, pmaxD,
-                                      S.epsilon, INFINITY, t, b1, b2, last) &&
-                        (t < ptmax || (t == ptmax && lprim > pseed) || pseed < 0)) {
-                      ptmax = t;
-                      pseed = lprim;
-                      pb1 = b1; pb2 = b2;
-                    }
-                  }
-                  if (pseed < 0) { want_probe = false; py = make_float4(0, 0, 0, 0); }
-                  else if (PROBE_ANY) {
-                    // The emitter is known, so is the term it gives if nothing hides it: the probe
-                    // becomes an occlusion ray whose hit clears the term (k_trace<true>), and a
-                    // term that is zero anyway (an emitter seen from behind) needs no ray at all.
-                    V3 y = probe_emitter_term(S, pseed, pos, mo, ptmax, pb1, pb2, mfr, mpdf, absdot);
-                    py = f4(y, 0.f);
-                    want_probe = !is_black(y);
+            // The probe only contributes when its closest hit is an emitter (no
+            // environment light here), so a ray that cannot reach one is not
+            // sent.  With few emitters their triangles are tested with the very
+            // test the traversal uses: if none is hit, the closest hit cannot be
+            // one; otherwise the ray starts out holding the nearest emitter hit,
+            // so that the traversal only looks for something at least as close.
+            if (!S.inf.valid) {
+              // first the padded box around all emitters: a ray that misses it cannot hit one
+              float tn;
+              bool reach = S.n_lights > 0 &&
+                           box_test(v3(S.emit_lo), v3(S.emit_hi), pos, v3(1.f / mo.x, 1.f / mo.y, 1.f / mo.z), INFINITY,
+                                    S.box_scale, tn);
+              if (!reach) {
+                want_probe = false;
+                py = make_float4(0, 0, 0, 0);
+              } else if (S.n_lights <= kProbeCullLights) {
+                float pmaxD = maxcomp(vabs(mo));
+                float pb1 = 0.f, pb2 = 0.f;
+                for (int li = 0; li < S.n_lights; ++li) {
+                  int lprim = __float_as_int(uniform_load4(S.lights + (size_t)li * kLightF4 + 4).w);
+                  const float4* rec = S.isect + (size_t)lprim * kIsectF4;
+                  float t, b1, b2;
+                  bool last;
+                  if (prim_test_rec(S, uniform_load4(rec), uniform_load4(rec + 1), uniform_load4(rec + 2), pos, mo, pmaxD,
+                                    S.epsilon, INFINITY, t, b1, b2, last) &&
+                      (t < ptmax || (t == ptmax && lprim > pseed) || pseed < 0)) {
+                    ptmax = t;
+                    pseed = lprim;
+                    pb1 = b1; pb2 = b2;
                   }
                 }
+                if (pseed < 0) { want_probe = false; py = make_float4(0, 0, 0, 0); }
+                else if (PROBE_ANY) {
+                  // The emitter is known, so is the term it gives if nothing hides it: the probe
+                  // becomes an occlusion ray whose hit clears the term (k_trace<true>), and a
+                  // term that is zero anyway (an emitter seen from behind) needs no ray at all.
+                  V3 y = probe_emitter_term(S, pseed, pos, mo, ptmax, pb1, pb2, mfr, mpdf, absdot);
+                  py = f4(y, 0.f);
+                  want_probe = !is_black(y);
+                }
               }
+            }
 #endif
-            }
-            // Li += beta * (x + y) is owed once visibility and the probe are known.
-            // Without a probe y counts as zero and is not stored; when x is zero
-            // as well the sum adds beta * 0, which only matters for a non-finite
-            // beta (the sample then turns NaN and is dropped), so a finite beta
-            // stores nothing at all.
-            bool finite_beta = fabsf(beta.x) < INFINITY && fabsf(beta.y) < INFINITY && fabsf(beta.z) < INFINITY;
-            if (want_probe || !is_black(x) || !finite_beta) {
-              P.pend_x[slot] = f4(x, absdot);
-              if (want_probe) P.pend_y[slot] = py;
-              P.beta_prev[slot] = f4(beta, 0.f);
-              flags |= kFPending | (want_probe ? kFPendingY : 0u);
-            }
           }
-          // continuation
-          V3 u;
-          u.x = rng_uniform(rng); u.y = rng_uniform(rng); u.z = rng_uniform(rng);
-          V3 wo2, fr2;
-          float pdf2;
-          sample_bsdf(S, m, -rd, nor, uv, dpdu, u, wo2, fr2, pdf2);
-          if (is_black(fr2)) {
-            alive = false;
-          } else {
-            beta = beta * (fr2 * fabsf(dot(nor, wo2)) / pdf2);
-            specular = is_delta(m.type);
-            no = pos; nd = wo2;
-            if (bounces > 3) {
-              float illumate = fps::clamp_(1.f - luminance(beta), 0.f, 1.f);
-              if (rng_uniform(rng) < illumate) alive = false;
-              else beta = beta / (1 - illumate);
-            }
-            if (bounces + 1 >= S.maxDepth) alive = false;
+          // Li += beta * (x + y) is owed once visibility and the probe are known.
+          // Without a probe y counts as zero and is not stored; when x is zero
+          // as well the sum adds beta * 0, which only matters for a non-finite
+          // beta (the sample then turns NaN and is dropped), so a finite beta
+          // stores nothing at all.
+          bool finite_beta = fabsf(beta.x) < INFINITY && fabsf(beta.y) < INFINITY && fabsf(beta.z) < INFINITY;
+          if (want_probe || !is_black(x) || !finite_beta) {
+            P.pend_x[slot] = f4(x, absdot);
+            if (want_probe) P.pend_y[slot] = py;
+            P.beta_prev[slot] = f4(beta, 0.f);
+            flags |= kFPending | (want_probe ? kFPendingY : 0u);
           }
         }
+        // continuation
+        if (is_black(fr2)) {
+          alive = false;
+        } else {
+          beta = beta * (fr2 * fabsf(dot(nor, wo2)) / pdf2);
+          specular = delta;
+          no = pos; nd = wo2;
+          if (bounces > 3) {
+            float illumate = fps::clamp_(1.f - luminance(beta), 0.f, 1.f);
+            if (rng_uniform(rng) < illumate) alive = false;
+            else beta = beta / (1 - illumate);
+          }
+          if (bounces + 1 >= S.maxDepth) alive = false;
+        }
       }
-      want_next = alive;
-      flags = (flags & ~(kFBounceMask | kFSpecular)) | (uint32_t)(bounces + 1) | (specular ? kFSpecular : 0u);
-      P.beta_rng[slot] = f4(beta, rng);
-      P.li_flags[slot] = f4(Li, flags);
     }
-    stage_push(stage.next, sbase, n_next, want_next, slot, no, -1, nd, INFINITY);
-    stage_push(stage.shadow, sbase_shadow, n_shadow, want_shadow, slot, so, -1, sd, stmax);
-    // Where every probe ray sets out knowing the nearest emitter on its line (few emitters, no
-    // environment), whether that emitter is the closest hit is a question of occlusion: is there
-    // a primitive in front of it, or at the same distance with a higher index?  Such a probe
-    // joins the shadow rays (any hit, early exit, two launches less per bounce), marked by the
-    // emitter's index where a shadow ray carries -1.
-    if (PROBE_ANY) {
-      stage_push(stage.shadow, sbase_shadow, n_shadow, want_probe, slot, po, pseed, pd, ptmax);
-      n_probe += (uint32_t)__popcll(__ballot(want_probe));
-    } else {
-      stage_push(stage.probe, sbase, n_probe, want_probe, slot, po, pseed, pd, ptmax);
+    want_next = alive;
+    flags = (flags & ~(kFBounceMask | kFSpecular)) | (uint32_t)(bounces + 1) | (specular ? kFSpecular : 0u);
+    P.beta_rng[slot] = f4(beta, rng);
+    P.li_flags[slot] = f4(Li, flags);
+  }
+  stage_push(stage.next, sc.base, sc.n_next, want_next, slot, no, -1, nd, INFINITY);
+  stage_push(stage.shadow, sc.base_shadow, sc.n_shadow, want_shadow, slot, so, -1, sd, stmax);
+  // Where every probe ray sets out knowing the nearest emitter on its line (few emitters, no
+  // environment), whether that emitter is the closest hit is a question of occlusion: is there
+  // a primitive in front of it, or at the same distance with a higher index?  Such a probe
+  // joins the shadow rays (any hit, early exit, two launches less per bounce), marked by the
+  // emitter's index where a shadow ray carries -1.
+  if (PROBE_ANY) {
+    stage_push(stage.shadow, sc.base_shadow, sc.n_shadow, want_probe, slot, po, pseed, pd, ptmax);
+    sc.n_probe += (uint32_t)__popcll(__ballot(want_probe));
+  } else {
+    stage_push(stage.probe, sc.base, sc.n_probe, want_probe, slot, po, pseed, pd, ptmax);
+  }
+}
+
+// The shade stage of the path tracer.
+//
+// Which queue entries need a vertex: a ray that hit nothing ends its path, and unless the scene has
+// an environment light nothing is left to do for it (what the path still owes from its previous
+// vertex is added by k_finish); in an open scene that is half the queue, and a vertex is some
+// 3000 vector instructions that those lanes would sit through.  So a wavefront first collects the
+// entries of a round that need a vertex in a short list in LDS and shades the list whenever it
+// holds 64: every lane of a group then has a vertex.  What is left in the list when the
+// wavefront's work is over is shaded as a partial group.  With CASTER_SHADE_SORT there is a list
+// per material type (and one for the misses an environment light makes count), so that all 64
+// lanes of a group run the same material's code; measured on the benchmark scene that is no gain
+// over the single list (neighbouring paths mostly meet the same material anyway, and rare
+// materials wait in their list until their rays are far apart): 1705-1720 against 1744 Msamples/s.
+// The wavefronts take chunks of CASTER_SHADE_CHUNK rounds round-robin, so that each sees a sample
+// of the whole image (a contiguous range per wavefront made the cost per wavefront follow the
+// image -- sky here, car paint there -- and the launch as long as its dearest range: -15 %).
+constexpr int kShadeLists = CASTER_SHADE_SORT ? 7 : 1;  // material types 0..5, misses under an environment light
+constexpr int kShadeListCap = 128;                      // a list is emptied as soon as it reaches 64: 63 + 64 at most
+template <bool PROBE_ANY>
+__global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
+  __shared__ uint32_t s_list[kShadeLists][kShadeListCap];
+  const DevScene& S = L.S;
+  const uint32_t count = *cur.count;
+  const uint32_t lane = threadIdx.x;
+  StageCursor sc{blockIdx.x * stage.region_cap, blockIdx.x * stage.shadow_region_cap, 0u, 0u, 0u};
+  // ring buffers: lane c keeps the start and the length of list c
+  uint32_t q_head = 0, q_len = 0;
+  const bool env = S.inf.valid != 0;
+  const uint32_t rounds_all = (count + kWave - 1) / kWave;
+  auto take_group = [&](int c, uint32_t n) {   // the first n (<= 64) entries of list c, one per lane
+    uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)q_head, c);
+    uint32_t my = s_list[c][(head + lane) & (kShadeListCap - 1)];
+    if ((int)lane == c) { q_head = (q_head + n) & (kShadeListCap - 1); q_len -= n; }
+    return my;
+  };
+  for (uint32_t c0 = blockIdx.x * CASTER_SHADE_CHUNK; c0 < rounds_all; c0 += gridDim.x * CASTER_SHADE_CHUNK) {
+    for (uint32_t r = c0; r < c0 + CASTER_SHADE_CHUNK && r < rounds_all; ++r) {
+      const uint32_t idx = r * kWave + lane;
+      int cls = -1;
+      if (idx < count) {
+        int prim = __float_as_int(cur.hit[idx].y);
+        if (prim >= 0) cls = CASTER_SHADE_SORT ? __float_as_int(S.shade[(size_t)prim * kShadeF4 + 7].y) : 0;
+        else if (env && cur.d[idx].w >= 0.f) cls = CASTER_SHADE_SORT ? 6 : 0;   // (tmax < 0: a slot outside the image)
+      }
+      unsigned long long todo = __ballot(cls >= 0);
+      while (todo) {
+        int first = __builtin_ctzll(todo);
+        int c = __builtin_amdgcn_readlane(cls, first);
+        unsigned long long mine = __ballot(cls == c);
+        uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)q_head, c);
+        uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)q_len, c);
+        if (cls == c)
+          s_list[c][(head + len + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))) & (kShadeListCap - 1)] = idx;
+        if ((int)lane == c) q_len += (uint32_t)__popcll(mine);
+        todo &= ~mine;
+      }
+      __syncthreads();
+      unsigned long long full = __ballot(lane < (uint32_t)kShadeLists && q_len >= (uint32_t)kWave);
+      while (full) {
+        int c = __builtin_ctzll(full);
+        uint32_t my = take_group(c, kWave);
+        shade_pt_vertices<PROBE_ANY>(L, cur, stage, sc, my, true);
+        full = __ballot(lane < (uint32_t)kShadeLists && q_len >= (uint32_t)kWave);
+      }
+      __syncthreads();
     }
   }
+  // what is left in the lists
+  for (int c = 0; c < kShadeLists; ++c) {
+    uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)q_len, c);
+    if (n == 0) continue;
+    uint32_t my = take_group(c, n);
+    shade_pt_vertices<PROBE_ANY>(L, cur, stage, sc, my, lane < n);
+  }
   __syncthreads();  // the copy below reads what other lanes of this wavefront staged
-  stage_flush(stage.next, sbase, n_next, out.next);
-  stage_flush(stage.shadow, sbase_shadow, n_shadow, out.shadow);
+  stage_flush(stage.next, sc.base, sc.n_next, out.next);
+  stage_flush(stage.shadow, sc.base_shadow, sc.n_shadow, out.shadow);
   if (PROBE_ANY) {
     // the probe queue stays empty; its length counter keeps the number of probe rays for the statistics
-    n_probe = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_probe);
-    if ((threadIdx.x & 63u) == 0 && n_probe) atomicAdd(out.probe.count, n_probe);
+    uint32_t n_probe = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.n_probe);
+    if (lane == 0 && n_probe) atomicAdd(out.probe.count, n_probe);
   } else {
-    stage_flush(stage.probe, sbase, n_probe, out.probe);
+    stage_flush(stage.probe, sc.base, sc.n_probe, out.probe);
   }
 }
 

@@ -1,5 +1,5 @@
-// Part of the gfx950 wavefront renderer (included by ../kernels.hip, in this order: common.h, traverse.h, trace.h, shading.h, path.h, volpath.h, lighttrace.h, bdpt.h, volpath_queues.h, film.h).
-// Intersection records, materials and textures, BSDF sample/eval, lights and light selection.
+// Part of the gfx950 wavefront renderer (included by ../kernels.hip, in this order: common.h, traverse.h, trace.h, shading.h, bsdf.h, path.h, volpath.h, lighttrace.h, bdpt.h, volpath_queues.h, film.h).
+// Intersection records, materials and textures, lights and light selection (scattering: bsdf.h).
 #pragma once
 
 namespace caster {
@@ -113,313 +113,15 @@ __device__ inline V3 albedo(const DevScene& S, const Mat& m, V2 uv) {
   return v3(r.x, r.y, r.z);
 }
 
-// --------------------------------------------------------------------- BSDFs
-// pathtracer.cu:45-178
-// The diffuse texture is looked up once per vertex: the BSDF functions below are
-// evaluated up to three times there (light sample, MIS sample, continuation)
-// with the same uv, and each would repeat the four texel fetches.
+// The diffuse texture is looked up once per vertex: its material is asked up to three times there
+// (light sample, MIS sample, continuation) with the same uv, and each would repeat the four texel
+// fetches.
 __device__ inline void resolve_texture(const DevScene& S, Mat& m, V2 uv) {
   if (m.tex != -1 && (m.type == 0 || m.type == 5)) {  // the materials that read it: Lambertian, Substrate
     m.diffuse = albedo(S, m, uv);
     m.tex = -1;
   }
 }
-__device__ inline V3 spherical_dir(float s, float c, float phi) { return v3(s * fps::cos_(phi), s * fps::sin_(phi), c); }
-__device__ inline float dielectric_fresnel(float cosi, float cost, float etai, float etat) {
-  float Rparl = (etat * cosi - etai * cost) / (etat * cosi + etai * cost);
-  float Rperp = (etai * cosi - etat * cost) / (etai * cosi + etat * cost);
-  return (Rparl * Rparl + Rperp * Rperp) * 0.5f;
-}
-__device__ inline V3 conduct_fresnel(float cosi, V3 eta, V3 k) {
-  V3 tmp = (eta * eta + k * k) * cosi * cosi;
-  V3 Rparl2 = (tmp - eta * cosi * 2.f + 1.f) / (tmp + eta * cosi * 2.f + 1.f);
-  V3 tmp_f = (eta * eta + k * k);
-  V3 Rperp2 = (tmp_f - eta * cosi * 2.f + cosi * cosi) / (tmp_f + eta * cosi * 2.f + cosi * cosi);
-  return (Rparl2 + Rperp2) * 0.5f;
-}
-__device__ inline float ggx_d(V3 wh, V3 normal, V3 dpdu, float alphaU, float alphaV) {
-  float costheta = dot(wh, normal);
-  if (costheta <= 0.f) return 0.f;
-  costheta = fps::clamp_(costheta, 0.f, 1.f);
-  float cos2Theta = costheta * costheta;
-  float sin2Theta = 1.f - cos2Theta;
-  float cos4Theta = cos2Theta * cos2Theta;
-  float tantheta2 = sin2Theta / cos2Theta;
-  V3 dir = normalize(wh - costheta * normal);
-  float cosphi = dot(dir, dpdu);
-  float e = tantheta2 * (cosphi * cosphi / (alphaU * alphaU) + (1.f - cosphi) / (alphaV * alphaV));
-  return 1.f / (PI * alphaU * alphaV * cos4Theta * (1 + e) * (1 + e));
-}
-__device__ inline float smith_g(V3 w, V3 normal, V3 wh, V3 dpdu, float alphaU, float alphaV) {
-  float wdn = dot(w, normal);
-  if (wdn * dot(w, wh) < 0.f) return 0.f;
-  float sinTheta = sqrtf(fps::clamp_(1.f - wdn * wdn, 0.f, 1.f));
-  float tanTheta = sinTheta / wdn;
-  if (isinf_(tanTheta)) return 0.f;
-  V3 dir = normalize(w - wdn * normal);
-  float cosPhi = dot(dir, dpdu);
-  float cos2Phi = cosPhi * cosPhi;
-  float sin2Phi = 1.f - cos2Phi;
-  float alpha2 = cos2Phi * (alphaU * alphaU) + sin2Phi * (alphaV * alphaV);
-  float alpha2Tan2Theta = alpha2 * tanTheta * tanTheta;
-  return 2.f / (1.f + sqrtf(1 + alpha2Tan2Theta));
-}
-__device__ inline float ggx_g(V3 wo, V3 wi, V3 normal, V3 wh, V3 dpdu, float aU, float aV) {
-  return smith_g(wo, normal, wh, dpdu, aU, aV) * smith_g(wi, normal, wh, dpdu, aU, aV);
-}
-__device__ inline V3 sample_ggx(float alphaU, float alphaV, float u1, float u2) {
-  if (alphaU == alphaV) {
-    float costheta = sqrtf((1.f - u1) / (u1 * (alphaU * alphaV - 1.f) + 1.f));
-    float sintheta = sqrtf(1.f - costheta * costheta);
-    float phi = TWOPI * u2;
-    return spherical_dir(sintheta, costheta, phi);
-  }
-  float phi = fps::atan_(alphaV / alphaU * fps::tan_(TWOPI * u2 + .5f * PI));
-  if (u2 > .5f) phi += PI;
-  float sinphi = fps::sin_(phi), cosphi = fps::cos_(phi);
-  const float alphaU2 = alphaU * alphaU;
-  const float alpha2 = 1.0f / (cosphi * cosphi / alphaU2 + sinphi * sinphi / alphaU2);
-  float tanTheta2 = alpha2 * u1 / (1.f - u1);
-  float costheta = 1 / sqrtf(1 + tanTheta2);
-  float sintheta = sqrtf(fps::fmax_(0.f, 1.f - costheta * costheta));
-  return spherical_dir(sintheta, costheta, phi);
-}
-__device__ inline V3 reflect(V3 in, V3 nor) { return 2.f * dot(in, nor) * nor - in; }
-__device__ inline V3 refract(V3 in, V3 nor, float etai, float etat) {
-  float cosi = dot(in, nor);
-  bool enter = cosi > 0;
-  if (!enter) { float t = etai; etai = etat; etat = t; }
-  float eta = etai / etat;
-  float sini2 = 1.f - cosi * cosi;
-  float sint2 = sini2 * eta * eta;
-  float cost = sqrtf(1.f - sint2);
-  return normalize((nor * cosi - in) * eta + (enter ? -cost : cost) * nor);
-}
-__device__ inline float pow5(float v) { return (v * v) * (v * v) * v; }
-__device__ inline V3 schlick(V3 Rs, float c) { return Rs + pow5(1.f - c) * (1 - Rs); }
-__device__ inline float power_heuristic(float fPdf, float gPdf) {
-  float f = 1 * fPdf, g = 1 * gPdf;
-  return (f * f) / (f * f + g * g);
-}
-__device__ inline float luminance(V3 c) { return dot(c, v3(0.212671f, 0.715160f, 0.072169f)); }
-__device__ inline bool same_hemisphere(V3 in, V3 out, V3 nor) { return dot(in, nor) * dot(out, nor) > 0; }
-__device__ inline bool is_delta(int t) { return t == 1 || t == 2; }  // mirror, dielectric
-
-// SampleBSDF (pathtracer.cu:500-698); `radiance` false is TransportMode::Importance (light paths),
-// which drops the radiance scaling of refraction (:549-550, :683-684).
-__device__ void sample_bsdf(const DevScene& S, const Mat& m, V3 in, V3 nor, V2 uv, V3 dpdu, V3 u, V3& out, V3& fr,
-                            float& pdf, bool radiance = true) {
-  switch (m.type) {
-    case 0: {  // lambertian
-      V3 n = nor;
-      if (dot(nor, in) < 0) n = -n;
-      out = cosine_hemisphere(u.x, u.y, pdf);
-      V3 uu = dpdu, ww = cross(uu, n);
-      out = to_world(out, uu, ww, n);
-      fr = albedo(S, m, uv) * ONE_OVER_PI;
-      break;
-    }
-    case 1:  // mirror
-      out = reflect(in, nor);
-      fr = m.specular / fabsf(dot(out, nor));
-      pdf = 1.f;
-      break;
-    case 2: {  // dielectric
-      V3 wi = -in;
-      V3 normal = nor;
-      float ei = m.outsideIOR, et = m.insideIOR;
-      float cosi = dot(wi, normal);
-      if (cosi > 0) { float t = et; et = ei; ei = t; }
-      float eta = ei / et;
-      float sint2 = eta * eta * (1.f - cosi * cosi);
-      float cost = sqrtf(1.f - sint2 < 0.f ? 0.f : 1.f - sint2);
-      V3 rdir = reflect(-wi, normal);
-      V3 tdir = refract(in, nor, m.outsideIOR, m.insideIOR);
-      if (sint2 > 1.f) {
-        out = rdir;
-        fr = m.specular / fabsf(dot(out, normal));
-        pdf = 1.f;
-        return;
-      }
-      float fresnel = dielectric_fresnel(fabsf(cost), fabsf(cosi), et, ei);
-      if (u.x > fresnel) {
-        out = tdir;
-        fr = m.specular / fabsf(dot(out, normal)) * (1.f - fresnel);
-        if (radiance) fr = fr * (eta * eta);
-        pdf = 1.f - fresnel;
-      } else {
-        out = rdir;
-        fr = m.specular / fabsf(dot(out, normal)) * fresnel;
-        pdf = fresnel;
-      }
-      break;
-    }
-    case 4: {  // rough conductor
-      V3 n = nor;
-      if (dot(nor, in) < 0) n = -n;
-      V3 wh = sample_ggx(m.alphaU, m.alphaV, u.x, u.y);
-      V3 uu = dpdu, ww = cross(uu, n);
-      wh = to_world(wh, uu, ww, n);
-      out = reflect(in, wh);
-      if (!same_hemisphere(in, out, nor)) { fr = v3(0, 0, 0); pdf = 0.f; return; }
-      float cosi = dot(out, wh);
-      V3 F = conduct_fresnel(fabsf(cosi), m.eta, m.k);
-      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
-      float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
-      fr = m.specular * F * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
-      pdf = D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(in, wh)));
-      break;
-    }
-    case 5: {  // substrate
-      V3 n = nor;
-      if (dot(nor, in) < 0) n = -n;
-      if (u.x < 0.5f) {
-        u.x = fps::fmin_(2.f * u.x, 0x1.fffffep-1f);
-        out = cosine_hemisphere(u.x, u.y, pdf);
-        V3 uu = dpdu, ww = cross(uu, n);
-        out = to_world(out, uu, ww, n);
-      } else {
-        u.x = fps::fmin_(2 * (u.x - 0.5f), 0x1.fffffep-1f);
-        V3 wh = sample_ggx(m.alphaU, m.alphaV, u.x, u.y);
-        V3 uu = dpdu, ww = cross(uu, n);
-        wh = to_world(wh, uu, ww, n);
-        out = reflect(in, wh);
-      }
-      if (!same_hemisphere(in, out, n)) { fr = v3(0, 0, 0); pdf = 0.f; return; }
-      float cosThetaWo = fabsf(dot(in, n));
-      float cosThetaWi = fabsf(dot(out, n));
-      V3 Rd = albedo(S, m, uv);
-      V3 Rs = m.specular;
-      V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) * (1 - pow5(1 - .5f * cosThetaWi)) *
-                   (1 - pow5(1 - .5f * cosThetaWo));
-      V3 wh = normalize(in + out);
-      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
-      float mx = cosThetaWi > cosThetaWo ? cosThetaWi : cosThetaWo;
-      V3 specular = D / (4.f * fabsf(dot(out, wh)) * mx) * schlick(Rs, dot(out, wh));
-      fr = diffuse + specular;
-      pdf = 0.5f * (fabsf(dot(out, n)) * ONE_OVER_PI + D * fabsf(dot(wh, n)) / (4.f * dot(in, wh)));
-      break;
-    }
-    case 3: {  // rough dielectric
-      V3 wo = -in;
-      V3 n = nor;
-      V3 wh = sample_ggx(m.alphaU, m.alphaV, u.x, u.y);
-      V3 uu = dpdu, ww = cross(uu, n);
-      wh = to_world(wh, uu, ww, n);
-      float ei = m.outsideIOR, et = m.insideIOR;
-      float cosi = dot(wo, n);
-      if (cosi > 0) { float t = et; et = ei; ei = t; }
-      float eta = ei / et;
-      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
-      float cosThetaI = dot(wo, wh);
-      float sin2ThetaI = fps::fmax_(0.f, 1.f - cosThetaI * cosThetaI);
-      float sin2ThetaT = eta * eta * sin2ThetaI;
-      float cosThetaT = sqrtf(1.f - sin2ThetaT < 0.f ? 0.f : 1.f - sin2ThetaT);
-      V3 rdir = reflect(-wo, wh);
-      V3 tdir = normalize((wo - wh * cosThetaI) * eta + (cosi < 0 ? -cosThetaT : cosThetaT) * wh);
-      if (sin2ThetaT > 1.f) {
-        out = rdir;
-        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
-        fr = m.specular * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
-        pdf = D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(wh, in)));
-        return;
-      }
-      float fresnel = dielectric_fresnel(fabsf(cosThetaI), fabsf(cosThetaT), ei, et);
-      if (u.z > fresnel) {
-        out = tdir;
-        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
-        float c = et * dot(out, wh) + ei * dot(in, wh);
-        fr = m.specular * ei * ei * D * G * (1.f - fresnel) * fabsf(dot(in, wh)) * fabsf(dot(out, wh)) /
-             (fabsf(dot(out, n)) * fabsf(dot(in, n)) * c * c);
-        if (radiance) fr = fr * (1.f / (eta * eta));
-        pdf = (1.f - fresnel) * D * fabsf(dot(wh, n)) * et * et * fabsf(dot(out, wh)) / (c * c);
-      } else {
-        out = rdir;
-        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
-        fr = m.specular * fresnel * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
-        pdf = D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(wh, in))) * fresnel;
-      }
-      break;
-    }
-    default:
-      out = v3(0, 0, 1); fr = v3(0, 0, 0); pdf = 0.f;
-  }
-}
-
-// Fr (pathtracer.cu:700-818)
-__device__ void eval_bsdf(const DevScene& S, const Mat& m, V3 in, V3 out, V3 nor, V2 uv, V3 dpdu, V3& fr, float& pdf) {
-  switch (m.type) {
-    case 0:
-      if (!same_hemisphere(in, out, nor)) { fr = v3(0, 0, 0); pdf = 0.f; return; }
-      fr = albedo(S, m, uv) * ONE_OVER_PI;
-      pdf = fabsf(dot(out, nor)) * ONE_OVER_PI;
-      break;
-    case 4: {
-      if (!same_hemisphere(in, out, nor)) { fr = v3(0, 0, 0); pdf = 0; return; }
-      V3 n = nor;
-      if (dot(nor, in) < 0) n = -n;
-      V3 wh = normalize(in + out);
-      float cosi = dot(out, wh);
-      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
-      float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
-      V3 F = conduct_fresnel(fabsf(cosi), m.eta, m.k);
-      fr = m.specular * F * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
-      pdf = D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(in, wh)));
-      break;
-    }
-    case 5: {
-      if (!same_hemisphere(in, out, nor)) { fr = v3(0, 0, 0); pdf = 0; return; }
-      V3 n = nor;
-      if (dot(nor, in) < 0) n = -n;
-      float cosThetaWo = fabsf(dot(in, n));
-      float cosThetaWi = fabsf(dot(out, n));
-      V3 Rd = albedo(S, m, uv);
-      V3 Rs = m.specular;
-      V3 diffuse = (28.f / (23.f * PI)) * Rd * (v3(1.f, 1.f, 1.f) - Rs) * (1 - pow5(1 - .5f * cosThetaWi)) *
-                   (1 - pow5(1 - .5f * cosThetaWo));
-      V3 wh = normalize(in + out);
-      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
-      float mx = cosThetaWi > cosThetaWo ? cosThetaWi : cosThetaWo;
-      V3 specular = D / (4.f * fabsf(dot(out, wh)) * mx) * schlick(Rs, dot(out, wh));
-      fr = diffuse + specular;
-      pdf = 0.5f * (fabsf(dot(out, n)) * ONE_OVER_PI + D * fabsf(dot(wh, n)) / (4.f * dot(in, wh)));
-      break;
-    }
-    case 3: {
-      V3 wo = -in;
-      V3 n = nor;
-      bool refl = dot(in, n) * dot(out, n) > 0;
-      float ei = m.outsideIOR, et = m.insideIOR;
-      float cosi = dot(wo, n);
-      if (cosi > 0) { float t = et; et = ei; ei = t; }
-      V3 wh = normalize(-(ei * in + et * out));
-      float eta = ei / et;
-      float D = ggx_d(wh, n, dpdu, m.alphaU, m.alphaV);
-      float cosThetaI = dot(wo, wh);
-      float sin2ThetaI = fps::fmax_(0.f, 1.f - cosThetaI * cosThetaI);
-      float sin2ThetaT = eta * eta * sin2ThetaI;
-      float cosThetaT = sqrtf(1.f - sin2ThetaT < 0.f ? 0.f : 1.f - sin2ThetaT);
-      float fresnel = dielectric_fresnel(fabsf(cosThetaI), fabsf(cosThetaT), ei, et);
-      if (!refl) {
-        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
-        float c = et * dot(out, wh) + ei * dot(in, wh);
-        fr = m.specular * ei * ei * D * G * (1.f - fresnel) * fabsf(dot(in, wh)) * fabsf(dot(out, wh)) /
-             (fabsf(dot(out, n)) * fabsf(dot(in, n)) * c * c);
-        fr = fr * (1.f / (eta * eta));
-        pdf = (1.f - fresnel) * D * fabsf(dot(wh, n)) * et * et * fabsf(dot(out, wh)) / (c * c);
-      } else {
-        float G = ggx_g(in, out, n, wh, dpdu, m.alphaU, m.alphaV);
-        fr = m.specular * fresnel * D * G / (4.f * fabsf(dot(in, n)) * fabsf(dot(out, n)));
-        pdf = fresnel * D * fabsf(dot(wh, n)) / (4.f * fabsf(dot(wh, in)));
-      }
-      break;
-    }
-    default:  // mirror, dielectric
-      fr = v3(0, 0, 0);
-      pdf = 0.f;
-  }
-}
-
 // -------------------------------------------------------------------- lights
 struct LightRec { V3 v0, v1, v2, n0, n1, n2, radiance; float area; int prim; };
 __device__ inline void load_light(const DevScene& S, int idx, LightRec& l) {

@@ -213,7 +213,9 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
       sh[1] = mk4(p.p1, p.w1);
     }
     sh[6] = make_float4(as_float(p.mat), as_float(p.light), as_float(p.med_in), as_float(p.med_out));
-    sh[7] = make_float4(as_float((uint32_t)p.type & kPrimTypeMask), 0, 0, 0);
+    // (the material's type rides along: the shade stage sorts hits by it before it loads anything else)
+    const int mat_type = p.mat >= 0 && p.mat < (int)sc.materials.size() ? sc.materials[p.mat].type : -1;
+    sh[7] = make_float4(as_float((uint32_t)p.type & kPrimTypeMask), as_float(mat_type), 0, 0);
   }
   A.lights.resize(sc.lights.size() * kLightF4);
   for (size_t i = 0; i < sc.lights.size(); ++i) {
@@ -409,7 +411,7 @@ static int alloc_lane(caster_renderer* r, Lane& ln) {
   // every shade wavefront owns a staging region large enough for all paths it can be given
   uint32_t rounds = (n + kWave - 1) / kWave;
   uint32_t per = (rounds + (uint32_t)r->shade_grid - 1) / (uint32_t)r->shade_grid;
-  ln.stage.region_cap = per * kWave;
+  ln.stage.region_cap = (per + CASTER_SHADE_CHUNK) * kWave;   // (chunks dealt round-robin: up to one chunk more than an even share)
   ln.stage.shadow_region_cap = r->probe_any ? 2 * ln.stage.region_cap : ln.stage.region_cap;
   uint32_t cap = ln.stage.region_cap * (uint32_t)r->shade_grid;
   if ((rc = alloc_queue(r, ln.stage.next, cap, false, nullptr))) return rc;
