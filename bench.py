@@ -162,8 +162,8 @@ def main():
     npix = scene.width * scene.height
     rows = (0, scene.height)
     if world > 1 and a.shard == "tile":
-        rows = sharding.row_band(scene.height, rank, world)
-        r.set_rows(*rows)
+        rows = sharding.row_stripes(scene.height, rank, world)
+        r.set_row_stripes(*rows)
 
     film = torch.empty(npix * 3, dtype=torch.float32, device="cuda:%d" % dev_index) if world > 1 else None
 
@@ -244,7 +244,7 @@ def main():
                 "spp_per_step": spp,
                 "sharding": ("none" if world == 1 else
                              "spp (disjoint iterations per rank, one film reduce)" if a.shard == "spp" else
-                             "tile (bands of scanlines per rank, one film reduce)"),
+                             "tile (slabs of 8 scanlines dealt round-robin over the ranks, one film reduce)"),
             },
             "kernel_ms": {k: v[0] for k, v in kt.items()},
             "kernel_launches": {k: v[1] for k, v in kt.items()},
@@ -337,7 +337,7 @@ def main():
                 raise caster.CasterError(0, "skipped (--no-exclusive)")
             r1 = caster.Renderer(scene, dev_index, r.iters_in_flight, 1)
             if rows != (0, scene.height):
-                r1.set_rows(*rows)
+                r1.set_row_stripes(*rows)
             n1 = r.iters_in_flight
             r1.render(1, n1, True)
             r1.reset_stats()

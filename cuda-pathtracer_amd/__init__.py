@@ -60,9 +60,9 @@ _lib = None
 # every symbol include/caster.h declares
 EXPORTS = [
     "caster_scene_load", "caster_scene_load_device", "caster_scene_get_bvh", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams",
-    "caster_set_rows",
+    "caster_set_rows", "caster_set_row_stripes",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
-    "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_trace_rays_static", "caster_get_stats", "caster_reset_stats",
+    "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_trace_rays_static", "caster_get_stats", "caster_get_walk_counts", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
     "caster_write_image", "caster_save_image", "caster_iters_in_flight",
 ]
@@ -107,6 +107,7 @@ def lib():
         L.caster_begin.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.caster_begin_streams.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.caster_set_rows.argtypes = [vp, C.c_int, C.c_int]
+        L.caster_set_row_stripes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.caster_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
         L.caster_render_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
         L.caster_sync.argtypes = [vp]
@@ -120,6 +121,7 @@ def lib():
                                         C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.caster_trace_rays_static.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
         L.caster_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.caster_get_walk_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.caster_reset_stats.argtypes = [vp]
         L.caster_set_profiling.argtypes = [vp, C.c_int]
         L.caster_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
@@ -193,6 +195,10 @@ class Renderer:
     def set_rows(self, y0, y1):
         _check(lib().caster_set_rows(self._h, y0, y1))
 
+    def set_row_stripes(self, y0, y1, rows, stride):
+        """Scanlines y0 <= y < y1 with (y - y0) % stride < rows (see sharding.row_stripes)."""
+        _check(lib().caster_set_row_stripes(self._h, y0, y1, rows, stride))
+
     def render(self, first_iter, n_iter=1, reset=False):
         _check(lib().caster_render(self._h, first_iter, n_iter, 1 if reset else 0))
 
@@ -243,6 +249,12 @@ class Renderer:
         st = Stats()
         _check(lib().caster_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def walk_counts(self):
+        """What the traversal kernel fetched: {closest, any} x {node records read from memory, primitive records tested}."""
+        a = (C.c_uint64 * 4)()
+        _check(lib().caster_get_walk_counts(self._h, a))
+        return {"closest": {"nodes": a[0], "prims": a[1]}, "any": {"nodes": a[2], "prims": a[3]}}
 
     def set_profiling(self, enable=True):
         _check(lib().caster_set_profiling(self._h, 1 if enable else 0))

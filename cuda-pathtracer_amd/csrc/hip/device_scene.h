@@ -73,7 +73,15 @@ struct DevScene {
   int integrator, maxDepth;
   float maxDist;
   int width, height;
-  int tiles_x, tiles_y;   // 8x8-pixel tiles: one tile per wavefront at generation
+  // The scanlines this renderer traces (sharding across GPUs): y0 <= y < y1 and (y - y0) % stride < rows, i.e.
+  // slabs of `rows` scanlines every `stride`; the whole image is (0, height, 1, 1).
+  int row_y0, row_y1, row_rows, row_stride;
+  // Path slots of one iteration are enumerated tile by tile (8x8 pixels: one tile per wavefront at generation)
+  // over the tile rows tile_row0 + (e / tile_rows) * tile_stride + e % tile_rows, e = 0 .. tiles_y - 1: every
+  // tile row of the image (0, 1, 1), or, where the scanline slabs are made of whole tile rows, only theirs,
+  // so that a renderer with an eighth of the image spends its path slots on an eighth of the image.
+  int tile_row0, tile_rows, tile_stride;
+  int tiles_x, tiles_y;   // tiles per tile row; tile rows enumerated
   int slots_per_iter;     // tiles_x * tiles_y * 64
 };
 
@@ -122,6 +130,10 @@ struct Stats {
   unsigned long long samples;
   unsigned long long invalid;
   unsigned long long stack_overflow;
+  // k_trace's own work, [closest hit, any hit]: 4-wide node records fetched from memory (the top of
+  // the tree is served from LDS) and primitive records tested
+  unsigned long long node_fetches[2];
+  unsigned long long prim_tests[2];
 };
 
 }  // namespace caster

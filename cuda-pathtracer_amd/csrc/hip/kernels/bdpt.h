@@ -426,7 +426,7 @@ __device__ inline uint32_t rng_skip(uint32_t x, uint32_t k) {
 // reached with a skip-ahead of the generator.  With a density grid in the scene the transmittance
 // of a join draws a data-dependent number of values, and every lane evaluates its own sample's
 // joins in order.
-__global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter, uint32_t n_iter, int y0, int y1, float* acc,
+__global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter, uint32_t n_iter, float* acc,
                                                 WalkAux aux, BdptStore V) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
   __shared__ uint32_t s_end[kWave + 1];  // joins of the samples of lanes < i
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter
     uint32_t k, local;
     batch_slot_split(S, idx, n_iter, k, local);
     uint32_t px, py;
-    const bool live = slot_pixel(S, local, px, py) && (int)py >= y0 && (int)py < y1;
+    const bool live = slot_pixel(S, local, px, py);
     uint32_t pixel = px + py * (uint32_t)S.width;
     uint32_t rng = 1u;
     int nCamera = 0, nLight = 0;

@@ -5,11 +5,14 @@
 namespace caster {
 
 constexpr int kWave = 64;
+#ifndef CASTER_TWO_RAYS
+#define CASTER_TWO_RAYS 0   // the traversal kernel holds two rays per lane (see k_trace)
+#endif
 #ifndef CASTER_LDS_DEPTH
-#define CASTER_LDS_DEPTH 10
+#define CASTER_LDS_DEPTH (CASTER_TWO_RAYS ? 7 : 10)
 #endif
 #ifndef CASTER_REFILL
-#define CASTER_REFILL 24
+#define CASTER_REFILL (CASTER_TWO_RAYS ? 40 : 24)
 #endif
 #ifndef CASTER_CHUNK
 #define CASTER_CHUNK 64
@@ -169,15 +172,24 @@ __device__ inline void primary_ray(const DevCamera& c, float x, float y, float a
 
 // Path slot <-> pixel: slots of one iteration are laid out tile by tile so a
 // wavefront's 64 primary rays cover an 8x8 pixel block.
+__device__ inline bool row_live(const DevScene& S, uint32_t py) {
+  if ((int)py < S.row_y0 || (int)py >= S.row_y1) return false;
+  return (py - (uint32_t)S.row_y0) % (uint32_t)S.row_stride < (uint32_t)S.row_rows;
+}
+// The pixel of slot `local`; false when the slot lies outside the image or on a scanline this renderer does not trace.
 __device__ inline bool slot_pixel(const DevScene& S, uint32_t local, uint32_t& px, uint32_t& py) {
   uint32_t tile = local >> 6, in = local & 63u;
-  uint32_t tx = tile % (uint32_t)S.tiles_x, ty = tile / (uint32_t)S.tiles_x;
+  uint32_t tx = tile % (uint32_t)S.tiles_x, e = tile / (uint32_t)S.tiles_x;
+  uint32_t ty = (uint32_t)S.tile_row0 + (e / (uint32_t)S.tile_rows) * (uint32_t)S.tile_stride + e % (uint32_t)S.tile_rows;
   px = tx * 8 + (in & 7u);
   py = ty * 8 + (in >> 3);
-  return px < (uint32_t)S.width && py < (uint32_t)S.height;
+  return px < (uint32_t)S.width && py < (uint32_t)S.height && row_live(S, py);
 }
+// The slot of a pixel on a traced scanline.
 __device__ inline uint32_t pixel_slot(const DevScene& S, uint32_t px, uint32_t py) {
-  uint32_t tile = (py >> 3) * (uint32_t)S.tiles_x + (px >> 3);
+  uint32_t d = (py >> 3) - (uint32_t)S.tile_row0;
+  uint32_t e = (d / (uint32_t)S.tile_stride) * (uint32_t)S.tile_rows + d % (uint32_t)S.tile_stride;
+  uint32_t tile = e * (uint32_t)S.tiles_x + (px >> 3);
   return (tile << 6) | ((py & 7u) << 3) | (px & 7u);
 }
 

@@ -9,12 +9,13 @@ namespace caster {
 // (pathtracer.cu:2502-2513): acc += colour of iteration first..first+n-1, in
 // iteration order.  A NaN/Inf sample adds nothing.  One thread per pixel, so
 // the sum order is fixed.
-__global__ void k_finish(LaunchCtx L, float* acc, uint32_t n_iter, int y0, int y1) {
+__global__ void k_finish(LaunchCtx L, float* acc, uint32_t n_iter) {
   const DevScene& S = L.S;
-  uint32_t npix = (uint32_t)S.width * (uint32_t)(y1 - y0);
+  uint32_t npix = (uint32_t)S.width * (uint32_t)(S.row_y1 - S.row_y0);
   uint32_t invalid = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-    uint32_t px = i % (uint32_t)S.width, py = (uint32_t)y0 + i / (uint32_t)S.width;
+    uint32_t px = i % (uint32_t)S.width, py = (uint32_t)S.row_y0 + i / (uint32_t)S.width;
+    if (!row_live(S, py)) continue;
     uint32_t local = pixel_slot(S, px, py);
     uint32_t pixel = px + py * (uint32_t)S.width;
     V3 a = v3(acc[3 * pixel], acc[3 * pixel + 1], acc[3 * pixel + 2]);

@@ -127,7 +127,7 @@ struct LtConn {
 enum { kLtSurface = 0, kLtMedium = 1, kLtStart = 2 };
 template <bool QUEUED>
 __global__ __launch_bounds__(kWave) void k_generate_lt(LaunchCtx L, RayQueue q, uint32_t first_iter, uint32_t n_iter,
-                                                       int y0, int y1, float* acc, WalkAux aux, LtConn conn) {
+                                                       float* acc, WalkAux aux, LtConn conn) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
   Stack st{s_stack, aux.spill + (blockIdx.x * kWave + threadIdx.x), aux.spill_stride, 0};
   const DevScene& S = L.S;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kWave) void k_generate_lt(LaunchCtx L, RayQueue q, 
     uint32_t k, local;
     batch_slot_split(S, idx, n_iter, k, local);
     uint32_t px, py;
-    bool live = slot_pixel(S, local, px, py) && (int)py >= y0 && (int)py < y1;
+    bool live = slot_pixel(S, local, px, py);
     uint32_t iter = first_iter + k;
     float4 o4 = make_float4(0, 0, 0, __int_as_float(-1)), d4 = make_float4(0, 0, 1, -1.f);
     uint32_t rng = 1u, flags = 0;

@@ -41,15 +41,14 @@ __device__ inline void batch_slot_split(const DevScene& S, uint32_t slot, uint32
 // Camera samples for iterations [first_iter, first_iter + n_iter): seeds the
 // RNG, draws the four camera numbers (pathtracer.cu:881-890), writes the
 // extension ray and fresh path state.  Queue index == path slot here.
-__global__ __launch_bounds__(kWave) void k_generate(LaunchCtx L, RayQueue q, uint32_t first_iter, uint32_t n_iter,
-                                                    int y0, int y1) {
+__global__ __launch_bounds__(kWave) void k_generate(LaunchCtx L, RayQueue q, uint32_t first_iter, uint32_t n_iter) {
   const DevScene& S = L.S;
   uint32_t total = (uint32_t)S.slots_per_iter * n_iter;
   for (uint32_t idx = blockIdx.x * kWave + threadIdx.x; idx < total; idx += gridDim.x * kWave) {
     uint32_t k, local;
     batch_slot_split(S, idx, n_iter, k, local);
     uint32_t px, py;
-    bool live = slot_pixel(S, local, px, py) && (int)py >= y0 && (int)py < y1;
+    bool live = slot_pixel(S, local, px, py);
     uint32_t iter = first_iter + k;
     float4 o4 = make_float4(0, 0, 0, __int_as_float(-1)), d4 = make_float4(0, 0, 1, -1.f);
     uint32_t rng = 1u;
@@ -81,23 +80,32 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 
 // Traces every ray of a queue with persistent wavefronts.
 //
-// A wavefront claims rays a chunk at a time from the queue's work counter and
-// keeps its 64 lanes fed: when kRefillIdle lanes have finished their rays the
-// idle lanes take the next unclaimed ones, so a long ray does not hold 63 idle
-// lanes hostage.  Between refills every step does the kind of work (a 4-wide
-// node, or one primitive test) that more lanes are waiting for.
+// A wavefront claims rays a chunk at a time from the queue's work counter and keeps its lanes fed:
+// when kRefillIdle of its ray slots are free they take the next unclaimed rays, so a long ray does
+// not hold the others hostage.  Between refills every step does the kind of work (a 4-wide node, or
+// one primitive test) that more lanes are waiting for.
+//
+// With CASTER_TWO_RAYS every lane holds two rays and takes part in a step when either of them can
+// (both live in registers; a step picks the operands of the one it advances with selects and puts
+// what changed back the same way).  The kernel is bound by vector instruction issue, and with one
+// ray per lane a step finds some 42 of 64 lanes with the kind of work the wavefront voted for: a ray
+// that waits for its last leaf sits through the node steps, one still descending through the
+// primitive steps.  Measured on the benchmark scene: 50 lanes per node step instead of 42, 16 %
+// fewer node steps and 14 % fewer primitive steps -- and launches 12 % LONGER (3.07 against 2.75
+// ms): the rays that can always advance finish sooner, so the lanes fill with rays that wait; the
+// selects add a tenth to every step; and 114 registers leave four wavefronts per SIMD, not five.
+// Exchanging the two register sets instead (v_swap_b32 under a narrowed execution mask) made the
+// compiler hold both sets in flight everywhere: 165 registers.  The default is one ray per lane.
 //   ANY=false: closest hit; (t, prim, b1, b2) goes into the queue entry.
 //   ANY=true:  any hit; an occluded ray clears the pending light-sampled term
 //              of its path.
-#ifndef CASTER_SPECULATE
-#define CASTER_SPECULATE 1
-#endif
 #ifndef CASTER_ANY_UNSORTED
 #define CASTER_ANY_UNSORTED 1
 #endif
 #ifndef CASTER_TRACE_WAVES
-#define CASTER_TRACE_WAVES 5
+#define CASTER_TRACE_WAVES (CASTER_TWO_RAYS ? 4 : 5)
 #endif
+constexpr int kTraceRays = CASTER_TWO_RAYS ? 2 : 1;   // rays per lane
 #ifdef CASTER_WALK_STATS
 // tuning aid: wavefront-level step counts of k_trace, [ANY][counter]
 __device__ unsigned long long g_walk_stats[2][8];
@@ -105,9 +113,31 @@ __device__ unsigned long long g_walk_stats[2][8];
 #else
 #define CASTER_WS(i, v)
 #endif
+// One ray of a lane.
+struct WalkRay {
+  V3 o, d, inv;
+  float maxD;
+  Hit hit;
+  int idx;   // queue entry; -1: the slot is free
+  int cur;   // where the ray stands: a node (>= 0), a leaf (~index of its next primitive), kRefEmpty
+  int pend;  // a leaf waiting for its primitives to be tested (same encoding), kRefEmpty
+  int sp;    // height of its stack
+  int occluded;
+};
+__device__ inline void walk_ray_idle(WalkRay& r) {
+  r.o = v3(0, 0, 0); r.d = v3(0, 0, 1); r.inv = v3(0, 0, 1); r.maxD = 1.f;
+  r.hit.t = 0.f; r.hit.prim = -1; r.hit.b1 = r.hit.b2 = 0.f;
+  r.idx = -1; r.cur = kRefEmpty; r.pend = kRefEmpty; r.sp = 0; r.occluded = 0;
+}
+__device__ inline float pick(bool second, float x0, float x1) { return second ? x1 : x0; }
+__device__ inline int pick(bool second, int x0, int x1) { return second ? x1 : x0; }
+__device__ inline V3 pick(bool second, V3 x0, V3 x1) { return v3(pick(second, x0.x, x1.x), pick(second, x0.y, x1.y), pick(second, x0.z, x1.z)); }
+__device__ inline void put(bool second, float& x0, float& x1, float v) { x0 = second ? x0 : v; x1 = second ? v : x1; }
+__device__ inline void put(bool second, int& x0, int& x1, int v) { x0 = second ? x0 : v; x1 = second ? v : x1; }
+
 template <bool ANY>
 __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
-  __shared__ uint2 s_stack[kTraceBlockWaves][kLdsDepth][kWave];
+  __shared__ uint2 s_stack[kTraceBlockWaves][kTraceRays * kLdsDepth][kWave];
   __shared__ float4 s_top[kTopNodes > 0 ? kTopNodes * kTopF4 : 1];
 #ifdef CASTER_WALK_STATS
   unsigned long long ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -125,16 +155,13 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       s_top[i] = S.nodes[(size_t)(i / kTopF4) * kNodeF4 + (i % kTopF4)];
     __syncthreads();
   }
-  Stack st{s_stack[wave_in_block], aux.spill + (wave_id * kWave + lane), aux.spill_stride, 0};
-  int idx = -1;
-  int cur = kRefEmpty;
-  int pend = kRefEmpty;  // a leaf waiting for its primitives to be tested
-  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), inv = v3(0, 0, 1);
+  Stack st{s_stack[wave_in_block], aux.spill + (wave_id * kWave + lane), aux.spill_stride, 0, 0};
+  WalkRay a, b;   // the lane's two rays; a's stack is stack 0, b's stack 1
+  walk_ray_idle(a);
+  walk_ray_idle(b);
   const float tmin = S.epsilon;
-  float maxD = 1.f;
-  Hit hit;
-  hit.t = 0.f; hit.prim = -1; hit.b1 = hit.b2 = 0.f;
-  bool occluded = false;
+  // node records fetched from memory and primitive records tested, for the statistics
+  uint32_t n_node_fetches = 0, n_prim_tests = 0;
   // this wavefront's first chunk is assigned statically (no atomic storm at
   // launch): the work counters start at the end of the static assignment
   const uint32_t part = ((count + kWorkShards - 1) / kWorkShards + kWave - 1) / kWave * kWave;
@@ -143,8 +170,6 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
   const uint32_t n_waves = gridDim.x * kTraceBlockWaves;
   const uint32_t per_wave = count / (n_waves * kChunk);
   const uint32_t chunk = per_wave >= 16 ? 4 * kChunk : per_wave >= 8 ? 2 * kChunk : kChunk;
-  // the work counters count from the end of the statically assigned first chunk of every wavefront
-  const uint32_t work_init = (n_waves + kWorkShards - 1) / kWorkShards * chunk;
   uint32_t shard = wave_id % kWorkShards, shards_tried = 0;
   uint32_t chunk_next, chunk_end;
   {
@@ -154,13 +179,13 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
     chunk_end = lo + base < hi ? (chunk_next + chunk < hi ? chunk_next + chunk : hi) : 0;
   }
   bool more = true;
-  for (;;) {
-    // retire finished rays
-    if (idx >= 0 && cur == kRefEmpty && pend == kRefEmpty) {
+  // Writes out ray `r` where it is finished.
+  auto retire = [&](WalkRay& r) {
+    if (r.idx >= 0 && r.cur == kRefEmpty && r.pend == kRefEmpty) {
       if (ANY) {
-        if (occluded) {
-          int slot = q.slot[idx];
-          if (hit.prim < 0) {
+        if (r.occluded) {
+          int slot = q.slot[r.idx];
+          if (r.hit.prim < 0) {
             float4 px = L.P.pend_x[slot];
             px.x = 0.f; px.y = 0.f; px.z = 0.f;
             L.P.pend_x[slot] = px;
@@ -171,144 +196,175 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
           }
         }
       } else {
-        q.hit[idx] = make_float4(hit.t, __int_as_float(hit.prim), hit.b1, hit.b2);
+        q.hit[r.idx] = make_float4(r.hit.t, __int_as_float(r.hit.prim), r.hit.b1, r.hit.b2);
       }
-      idx = -1;
+      r.idx = -1;
     }
-    // refill idle lanes
-    unsigned long long idle_mask = __ballot(idx < 0);
+  };
+  // Gives the lanes whose slot `r` is free the next unclaimed rays.
+  auto refill = [&](WalkRay& r) {
+    unsigned long long idle_mask = __ballot(r.idx < 0);
     uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-    if (more && n_idle >= (uint32_t)kRefillIdle) {
-      if (chunk_next == chunk_end) {
-        // Claim the next chunk.  The queue is cut into kWorkShards contiguous
-        // parts with a work counter each: same-address atomics with a return
-        // value retire at only ~15 per microsecond on this chip, so one shared
-        // counter would bound the kernel.  A wavefront works on "its" part
-        // first and moves on to the next part when that one is exhausted.
-        while (shards_tried < kWorkShards) {
-          uint32_t lo = shard * part, hi = lo + part < count ? lo + part : count;
-          // A part whose rays were all handed out statically needs no atomic to be found empty: in a
-          // launch over a short queue that is every part, and 5120 wavefronts asking eight counters
-          // in turn would take longer than the tracing (same-address atomics retire at ~20 per us).
-          if (lo + work_init < hi) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(aux.work + shard * kWorkPad, chunk);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + work_init;
-            if (lo + base < hi) {
-              chunk_next = lo + base;
-              chunk_end = chunk_next + chunk < hi ? chunk_next + chunk : hi;
-              break;
-            }
+    if (!more || n_idle == 0) return;
+    if (chunk_next == chunk_end) {
+      // Claim the next chunk.  The queue is cut into kWorkShards contiguous
+      // parts with a work counter each: same-address atomics with a return
+      // value retire at only ~15 per microsecond on this chip, so one shared
+      // counter would bound the kernel.  A wavefront works on "its" part
+      // first and moves on to the next part when that one is exhausted.
+      while (shards_tried < kWorkShards) {
+        uint32_t lo = shard * part, hi = lo + part < count ? lo + part : count;
+        // the counter of a part counts from the end of what was handed out statically: one chunk
+        // to each of the wavefronts whose first part it is
+        const uint32_t work_init = (n_waves - shard + kWorkShards - 1) / kWorkShards * chunk;
+        // A part whose rays were all handed out statically needs no atomic to be found empty: in a
+        // launch over a short queue that is every part, and thousands of wavefronts asking eight
+        // counters in turn would take longer than the tracing (same-address atomics retire at ~20 per us).
+        if (lo + work_init < hi) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(aux.work + shard * kWorkPad, chunk);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + work_init;
+          if (lo + base < hi) {
+            chunk_next = lo + base;
+            chunk_end = chunk_next + chunk < hi ? chunk_next + chunk : hi;
+            break;
           }
-          shard = shard + 1 == kWorkShards ? 0 : shard + 1;
-          ++shards_tried;
         }
-        if (shards_tried == kWorkShards) more = false;
+        shard = shard + 1 == kWorkShards ? 0 : shard + 1;
+        ++shards_tried;
       }
-      if (more) {
-        uint32_t avail = chunk_end - chunk_next;
-        uint32_t give = avail < n_idle ? avail : n_idle;
-        uint32_t prefix = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-        if (idx < 0 && prefix < give) {
-          idx = (int)(chunk_next + prefix);
-          float4 o4 = q.o[idx], d4 = q.d[idx];
-          o = v3(o4); d = v3(d4);
-          inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-          maxD = maxcomp(vabs(d));
-          // every queued ray starts at the scene's epsilon; o.w carries a hit known
-          // beforehand (a probe ray's nearest emitter, at distance tmax) or -1
-          hit.t = d4.w; hit.prim = __float_as_int(o4.w); hit.b1 = hit.b2 = 0.f;
-          occluded = false;
-          st.sp = 0;
-          // tmax < 0 marks a camera slot outside the image: nothing to trace.  (A tmax that is not
-          // a number -- a light sample at the vertex itself -- bounds nothing: every comparison with
-          // it fails, in the slab test and in the primitive tests, and the ray is traced unbounded,
-          // as the reference traces it.)
-          cur = (!(d4.w < 0.f) && S.n_nodes) ? 0 : kRefEmpty;
-        }
-        chunk_next += give;
-      }
+      if (shards_tried == kWorkShards) { more = false; return; }
+    }
+    uint32_t avail = chunk_end - chunk_next;
+    uint32_t give = avail < n_idle ? avail : n_idle;
+    uint32_t prefix = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+    if (r.idx < 0 && prefix < give) {
+      r.idx = (int)(chunk_next + prefix);
+      float4 o4 = q.o[r.idx], d4 = q.d[r.idx];
+      r.o = v3(o4); r.d = v3(d4);
+      r.inv = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+      r.maxD = maxcomp(vabs(r.d));
+      // every queued ray starts at the scene's epsilon; o.w carries a hit known
+      // beforehand (a probe ray's nearest emitter, at distance tmax) or -1
+      r.hit.t = d4.w; r.hit.prim = __float_as_int(o4.w); r.hit.b1 = r.hit.b2 = 0.f;
+      r.occluded = 0;
+      r.pend = kRefEmpty;
+      r.sp = 0;
+      // tmax < 0 marks a camera slot outside the image: nothing to trace.  (A tmax that is not
+      // a number -- a light sample at the vertex itself -- bounds nothing: every comparison with
+      // it fails, in the slab test and in the primitive tests, and the ray is traced unbounded,
+      // as the reference traces it.)
+      r.cur = (!(d4.w < 0.f) && S.n_nodes) ? 0 : kRefEmpty;
+    }
+    chunk_next += give;
+  };
+  for (;;) {
+    // finished rays leave
+    retire(a);
+    if (kTraceRays == 2) retire(b);
+    // free slots are refilled once there are enough of them
+    uint32_t n_idle = (uint32_t)__popcll(__ballot(a.idx < 0)) + (kTraceRays == 2 ? (uint32_t)__popcll(__ballot(b.idx < 0)) : 0u);
+    if (more && n_idle >= (uint32_t)kRefillIdle) {
+      refill(a);
+      if (kTraceRays == 2) refill(b);
     }
     CASTER_WS(6, 1);
-    if (!__any(idx >= 0)) {
+    if (!__any(a.idx >= 0 || b.idx >= 0)) {
       if (!more) break;
       continue;
     }
-    // Advance until enough lanes are free again.  Each step the wavefront does
-    // whichever kind of work more of its lanes can do: one 4-wide node for every
-    // lane that stands at an inner node, or one primitive test for every lane
-    // that holds a leaf.  A lane that reaches a leaf parks it in `pend` (a leaf
-    // reference is ~index of the next primitive to test, so the cursor lives in
-    // the reference itself) and goes on with the next deferred node, so that it
-    // keeps taking part in node steps; the parked leaf may later shorten the ray
-    // and make some of that node work unnecessary, never wrong.
+    // Advance until enough slots are free again.  Each step the wavefront does whichever kind of
+    // work more of its lanes can do: one 4-wide node for every lane with a ray that stands at an
+    // inner node, or one primitive test for every lane with a ray that holds a leaf.  A ray that
+    // stands at a leaf parks it in `pend` (a leaf reference is ~index of the next primitive to test,
+    // so the cursor lives in the reference itself) and goes on with its next deferred node, so that
+    // it keeps taking part in node steps; the parked leaf may later shorten the ray and make some of
+    // that node work unnecessary, never wrong.  Every ray is kept in that state: one that stands at
+    // a leaf has a parked leaf already.
     for (;;) {
-#if CASTER_SPECULATE
-      if (cur < 0 && cur != kRefEmpty && pend == kRefEmpty) {
-        pend = cur;
-        cur = stack_next(st, lane, hit.t);
-      }
-      unsigned long long m_inner = __ballot(cur >= 0);
-      unsigned long long m_leaf = __ballot(pend != kRefEmpty);
-      unsigned long long m_busy = __ballot(cur != kRefEmpty || pend != kRefEmpty);
-      int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf);
-      int n_free = kWave - __popcll(m_busy);
-      if (m_busy == 0) break;
-      if (more && n_free >= kRefillIdle) break;
-      CASTER_WS(4, __popcll(m_busy));
-      CASTER_WS(5, __popcll(m_inner & m_leaf));
+      const bool node_a = a.cur >= 0, node_b = kTraceRays == 2 && b.cur >= 0;
+      const bool leaf_a = a.pend != kRefEmpty, leaf_b = kTraceRays == 2 && b.pend != kRefEmpty;
+      const int n_inner = __popcll(__ballot(node_a || node_b)), n_leaf = __popcll(__ballot(leaf_a || leaf_b));
+      const int n_busy = __popcll(__ballot(a.cur != kRefEmpty || a.pend != kRefEmpty)) +
+                         (kTraceRays == 2 ? __popcll(__ballot(b.cur != kRefEmpty || b.pend != kRefEmpty)) : 0);
+      if (n_busy == 0) break;
+      if (more && kTraceRays * kWave - n_busy >= kRefillIdle) break;
+      CASTER_WS(4, n_busy);
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
         CASTER_WS(0, 1);
         CASTER_WS(1, n_inner);
-        if (cur >= 0) cur = node_step<!ANY || !CASTER_ANY_UNSORTED>(S, cur, o, inv, hit.t, st, lane, overflow, s_top, n_top);
-      } else if (pend != kRefEmpty) {
+        // the lane's first ray if it stands at a node, else its second
+        const bool w = kTraceRays == 2 && !node_a;
+        int cur = pick(w, a.cur, b.cur);
+        n_node_fetches += (uint32_t)__popcll(__ballot(cur >= n_top));
+        if (cur >= 0) {
+          const V3 o = pick(w, a.o, b.o), inv = pick(w, a.inv, b.inv);
+          const float tmax = pick(w, a.hit.t, b.hit.t);
+          int pend = pick(w, a.pend, b.pend);
+          st.sp = pick(w, a.sp, b.sp);
+          st.ctx = w ? 1 : 0;
+          cur = node_step<!ANY || !CASTER_ANY_UNSORTED>(S, cur, o, inv, tmax, st, lane, overflow, s_top, n_top);
+          if (cur < 0 && cur != kRefEmpty && pend == kRefEmpty) {
+            pend = cur;
+            cur = stack_next(st, lane, tmax);
+          }
+          put(w, a.cur, b.cur, cur);
+          put(w, a.pend, b.pend, pend);
+          put(w, a.sp, b.sp, st.sp);
+        }
+      } else {
         CASTER_WS(2, 1);
         CASTER_WS(3, n_leaf);
-        int i = ~pend;
-        float t, b1, b2;
-        bool last;
-        bool found = prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last);
-        if (found) {
+        const bool w = kTraceRays == 2 && !leaf_a;
+        int pend = pick(w, a.pend, b.pend);
+        n_prim_tests += (uint32_t)__popcll(__ballot(pend != kRefEmpty));
+        if (pend != kRefEmpty) {
+          const V3 o = pick(w, a.o, b.o), d = pick(w, a.d, b.d);
+          const float maxD = pick(w, a.maxD, b.maxD);
+          float ht = pick(w, a.hit.t, b.hit.t);
+          const int hp = pick(w, a.hit.prim, b.hit.prim);
+          int cur = pick(w, a.cur, b.cur);
+          int i = ~pend;
+          float t, b1, b2;
+          bool last;
+          bool found = prim_test(S, i, o, d, maxD, tmin, ht, t, b1, b2, last);
           // (an occlusion ray holds -1 in hit.prim, or the emitter a probe ray was sent to, at
           // distance hit.t: the emitter itself and what it hides at equal distance do not occlude)
+          const bool better = found && (t < ht || i > hp);
           if (ANY) {
-            if (t < hit.t || i > hit.prim) occluded = true;
-          } else if (t < hit.t || i > hit.prim) {
-            hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2;
+            if (better) {
+              put(w, a.occluded, b.occluded, 1);
+              cur = kRefEmpty;
+              pend = kRefEmpty;
+            } else {
+              pend = last ? kRefEmpty : ~(i + 1);
+            }
+          } else {
+            if (better) {
+              ht = t;
+              put(w, a.hit.t, b.hit.t, t); put(w, a.hit.prim, b.hit.prim, i);
+              put(w, a.hit.b1, b.hit.b1, b1); put(w, a.hit.b2, b.hit.b2, b2);
+            }
+            pend = last ? kRefEmpty : ~(i + 1);
           }
-        }
-        if (ANY && occluded) {
-          cur = kRefEmpty;
-          pend = kRefEmpty;
-        } else {
-          pend = last ? kRefEmpty : ~(i + 1);
+          if (cur < 0 && cur != kRefEmpty && pend == kRefEmpty) {   // the ray stands at another leaf already
+            st.sp = pick(w, a.sp, b.sp);
+            st.ctx = w ? 1 : 0;
+            pend = cur;
+            cur = stack_next(st, lane, ht);
+            put(w, a.sp, b.sp, st.sp);
+          }
+          put(w, a.cur, b.cur, cur);
+          put(w, a.pend, b.pend, pend);
         }
       }
-#else
-      unsigned long long m_inner = __ballot(cur >= 0);
-      unsigned long long m_leaf = __ballot(cur < 0 && cur != kRefEmpty);
-      int n_inner = __popcll(m_inner), n_leaf = __popcll(m_leaf);
-      int n_free = kWave - n_inner - n_leaf;
-      if (n_inner + n_leaf == 0) break;
-      if (more && n_free >= kRefillIdle) break;
-      if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
-        if (cur >= 0) cur = node_step<!ANY || !CASTER_ANY_UNSORTED>(S, cur, o, inv, hit.t, st, lane, overflow, s_top, n_top);
-      } else if (cur < 0 && cur != kRefEmpty) {
-        int i = ~cur;
-        float t, b1, b2;
-        bool last;
-        bool found = prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last);
-        if (found) {
-          if (ANY) {
-            if (t < hit.t || i > hit.prim) occluded = true;
-          } else if (t < hit.t || i > hit.prim) {
-            hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2;
-          }
-        }
-        if (ANY && occluded) cur = kRefEmpty;
-        else cur = last ? stack_next(st, lane, hit.t) : ~(i + 1);
-      }
-#endif
+    }
+  }
+  if (n_node_fetches | n_prim_tests) {
+    // (both are sums of wavefront-wide counts, the same in every lane)
+    if (lane == 0) {
+      atomicAdd(&L.stats->node_fetches[ANY ? 1 : 0], (unsigned long long)n_node_fetches);
+      atomicAdd(&L.stats->prim_tests[ANY ? 1 : 0], (unsigned long long)n_prim_tests);
     }
   }
 #ifdef CASTER_WALK_STATS

@@ -149,6 +149,8 @@ struct Stack {
   uint2* spill;  // this lane's column
   uint32_t stride;
   int sp;
+  int ctx = 0;   // k_trace keeps two rays per lane: which of the lane's two stacks this is (rows ctx * kLdsDepth of
+                 // `lds`, rows ctx * kSpillDepth of the spill column)
 };
 #ifndef CASTER_STACK_SPLIT
 #define CASTER_STACK_SPLIT 1
@@ -159,20 +161,20 @@ struct Stack {
 // otherwise merge the LDS and the spill branch into 32-bit flat accesses.
 typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64_t;
 __device__ inline void lds_put(Stack& s, int sp, uint32_t lane, uint2 e) {
-  *(lds_u64_t*)&s.lds[sp][lane] = ((unsigned long long)e.y << 32) | e.x;
+  *(lds_u64_t*)&s.lds[s.ctx * kLdsDepth + sp][lane] = ((unsigned long long)e.y << 32) | e.x;
 }
 __device__ inline uint2 lds_get(Stack& s, int sp, uint32_t lane) {
-  unsigned long long v = *(lds_u64_t*)&s.lds[sp][lane];
+  unsigned long long v = *(lds_u64_t*)&s.lds[s.ctx * kLdsDepth + sp][lane];
   return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 #else
-__device__ inline void lds_put(Stack& s, int sp, uint32_t lane, uint2 e) { s.lds[sp][lane] = e; }
-__device__ inline uint2 lds_get(Stack& s, int sp, uint32_t lane) { return s.lds[sp][lane]; }
+__device__ inline void lds_put(Stack& s, int sp, uint32_t lane, uint2 e) { s.lds[s.ctx * kLdsDepth + sp][lane] = e; }
+__device__ inline uint2 lds_get(Stack& s, int sp, uint32_t lane) { return s.lds[s.ctx * kLdsDepth + sp][lane]; }
 #endif
 __device__ inline bool stack_push(Stack& s, uint32_t lane, int ref, float tn) {
   uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
   if (s.sp < kLdsDepth) lds_put(s, s.sp, lane, e);
-  else if (s.sp < kLdsDepth + kSpillDepth) s.spill[(size_t)(s.sp - kLdsDepth) * s.stride] = e;
+  else if (s.sp < kLdsDepth + kSpillDepth) s.spill[(size_t)(s.ctx * kSpillDepth + s.sp - kLdsDepth) * s.stride] = e;
   else return false;
   ++s.sp;
   return true;
@@ -186,7 +188,7 @@ __device__ inline int stack_next(Stack& s, uint32_t lane, float tmax) {
     --s.sp;
     uint2 e;
     if (s.sp < kLdsDepth) e = lds_get(s, s.sp, lane);
-    else e = s.spill[(size_t)(s.sp - kLdsDepth) * s.stride];
+    else e = s.spill[(size_t)(s.ctx * kSpillDepth + s.sp - kLdsDepth) * s.stride];
     if (!(__uint_as_float(e.y) > tmax * fps::kNearCullSlack)) return (int)e.x;  // the slab test's own cull, with the ray's present tmax
   }
   return kRefEmpty;

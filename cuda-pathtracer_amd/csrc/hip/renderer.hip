@@ -338,7 +338,10 @@ struct caster_renderer {
   uint32_t pool_slots = 0;
   uint32_t iterations = 0;
   uint64_t samples = 0;
-  int y0 = 0, y1 = 0;
+  DevScene S_full{};         // S with the whole image as the row set (first-hit maps are always of the whole image)
+  uint32_t live_pixels = 0;  // pixels on the scanlines this renderer traces
+  int batch_iters = 1;       // iterations per batch: the path pool holds iters_in_flight iterations of the whole image,
+                             // and more of a part of it
   int n_cu = 256;
   // optional per-kernel-class timing with HIP events on the render streams
   bool profiling = false;
@@ -417,8 +420,10 @@ static int alloc_lane(caster_renderer* r, Lane& ln) {
   if ((rc = alloc_queue(r, ln.stage.next, cap, false, nullptr))) return rc;
   if ((rc = alloc_queue(r, ln.stage.shadow, ln.stage.shadow_region_cap * (uint32_t)r->shade_grid, false, nullptr))) return rc;
   if ((rc = alloc_queue(r, ln.stage.probe, r->probe_any ? kWave : cap, false, nullptr))) return rc;
-  ln.aux.spill_stride = (uint32_t)r->walk_grid * kWave;
-  if ((rc = dev_alloc(r, &ln.aux.spill, (size_t)ln.aux.spill_stride * kSpillDepth))) return rc;
+  // stack spill columns, one per lane of the widest grid that walks the tree (the traversal kernel, and the shade-grid
+  // and bidirectional kernels that walk in place); the traversal kernel keeps kTraceRays stacks per lane
+  ln.aux.spill_stride = (uint32_t)std::max(r->walk_grid, std::max(r->shade_grid, r->bdpt_grid)) * kWave;
+  if ((rc = dev_alloc(r, &ln.aux.spill, (size_t)ln.aux.spill_stride * kSpillDepth * kTraceRays))) return rc;
   ln.aux.work = ln.counters + 64;
   if (r->S.integrator == IT_BDPT) {
     ln.bdpt.stride = (uint32_t)r->bdpt_grid * kWave;
@@ -495,7 +500,9 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   S.width = sc.width; S.height = sc.height;
   S.tiles_x = (sc.width + 7) / 8; S.tiles_y = (sc.height + 7) / 8;
   S.slots_per_iter = S.tiles_x * S.tiles_y * 64;
-  r->y0 = 0; r->y1 = sc.height;
+  S.row_y0 = 0; S.row_y1 = sc.height; S.row_rows = 1; S.row_stride = 1;
+  S.tile_row0 = 0; S.tile_rows = 1; S.tile_stride = 1;
+  r->live_pixels = (uint32_t)sc.width * (uint32_t)sc.height;
 
   const bool default_pool = iters_in_flight <= 0;
   if (default_pool) {
@@ -518,7 +525,12 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
       iters_in_flight = (int)std::max<long long>(1, std::min<long long>(iters_in_flight, fit));
     }
   }
+  // queue entries and path slots are 32-bit signed indices (the shadow queue holds two per slot when the probe
+  // rays ride it): a batch beyond that is refused, not wrapped
+  if ((uint64_t)S.slots_per_iter * (uint64_t)iters_in_flight * 2u > (uint64_t)INT32_MAX)
+    return fail(CASTER_ERR_ARG, "caster_begin: iters_in_flight * pixels exceeds the 2^30 path slots a renderer can index");
   r->iters_in_flight = iters_in_flight;
+  r->batch_iters = iters_in_flight;
   r->pool_slots = (uint32_t)S.slots_per_iter * (uint32_t)iters_in_flight;
   // shade grid: one wavefront per block, as many as are resident at once
   {
@@ -541,13 +553,13 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
                      : sc.integrator == IT_LT ? (r->lt_queues ? (const void*)k_shade_lt<true> : (const void*)k_shade_lt<false>)
                                               : (const void*)k_shade_pt<false>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-    if (per_cu > 20) per_cu = 20;  // the vpt shade stage indexes the spill area sized for 20 wavefronts per CU
+    if (per_cu > 20) per_cu = 20;
     r->shade_grid = r->n_cu * per_cu;
   }
   // persistent traversal grid: as many wavefronts as LDS stacks and registers allow per CU
   {
     // per workgroup: kTraceBlockWaves stacks and one copy of the top of the tree
-    int lds_per_block = kTraceBlockWaves * kLdsDepth * kWave * 8 + std::max(kTopNodes, 1) * kTopF4 * 16;
+    int lds_per_block = kTraceBlockWaves * kTraceRays * kLdsDepth * kWave * 8 + std::max(kTopNodes, 1) * kTopF4 * 16;
     int by_lds = (160 * 1024) / lds_per_block * kTraceBlockWaves;
     int by_regs = CASTER_TRACE_WAVES * 4 / kTraceBlockWaves * kTraceBlockWaves;
     r->walk_grid = r->n_cu * std::max(kTraceBlockWaves, std::min(by_lds, by_regs));
@@ -568,6 +580,7 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   HIPCHECK(hipMemset(r->acc, 0, npix * 3 * sizeof(float)));
   if ((rc = dev_alloc(r, &r->film_tmp, npix * 3))) return rc;
   if ((rc = dev_alloc(r, &r->ids, npix))) return rc;
+  r->S_full = r->S;
   return CASTER_OK;
 }
 
@@ -626,7 +639,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
     // stream at once, as light tracing does): nothing to submit in the second half
     if (!tail) {
       ScopedTimer t(r, st, CASTER_K_SHADE);
-      hipLaunchKernelGGL(k_bdpt, dim3(r->bdpt_grid), dim3(kWave), 0, st, L, first, n, r->y0, r->y1, r->acc, ln.aux, ln.bdpt);
+      hipLaunchKernelGGL(k_bdpt, dim3(r->bdpt_grid), dim3(kWave), 0, st, L, first, n, r->acc, ln.aux, ln.bdpt);
       ln.batch_first = first; ln.batch_n = n;
     }
     HIPCHECK(hipGetLastError());
@@ -637,13 +650,13 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
       ScopedTimer t(r, st, CASTER_K_GENERATE);
       if (S.integrator == IT_LT)  // walks the first camera connection: one stack per wavefront of the shade grid
         if (r->lt_queues)
-          hipLaunchKernelGGL(k_generate_lt<true>, dim3(r->shade_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1,
+          hipLaunchKernelGGL(k_generate_lt<true>, dim3(r->shade_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n,
                              r->acc, ln.aux, LtConn{ln.shadow, ln.probe, ln.stage});
         else
-          hipLaunchKernelGGL(k_generate_lt<false>, dim3(r->shade_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1,
+          hipLaunchKernelGGL(k_generate_lt<false>, dim3(r->shade_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n,
                              r->acc, ln.aux, LtConn{});
       else
-        hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n, r->y0, r->y1);
+        hipLaunchKernelGGL(k_generate, dim3(gen_grid), dim3(kWave), 0, st, L, ln.ext[0], first, n);
     }
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, total);
     // (light tracing on queues: the shadow queue and the list already hold the connections of the
@@ -652,8 +665,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
                        (const uint32_t*)nullptr, ln.ext[1].count, r->lt_queues ? (uint32_t*)nullptr : ln.shadow.count,
                        r->lt_queues ? (uint32_t*)nullptr : ln.probe.count, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init, 0u);
   }
-  const uint32_t live_rays = (uint32_t)S.width * (uint32_t)(r->y1 - r->y0) * n;
-  bool failed = false;
+  const uint32_t live_rays = r->live_pixels * n;
   // One round of the volumetric integrator with everything on queues: the shadow rays are
   // advanced a Tr() segment at a time (closest-hit pass, then k_tr_step) until none is left.
   auto bounce_vptq = [&](int b) {
@@ -785,7 +797,6 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
       for (int k = 0; k < 4; ++k, ++b) bounce(b);
     }
   }
-  if (failed) return fail(CASTER_ERR_DEVICE, "reading a queue length failed");
   if (S.integrator == IT_LT) {
     // light paths have splatted their contributions into the film as they went (float atomics,
     // from every stream at once): there is no per-pixel colour to add, and a read-modify-write
@@ -797,7 +808,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
   if (r->last_finish && r->last_finish != ln.finish_done) HIPCHECK(hipStreamWaitEvent(st, r->last_finish, 0));
   {
     ScopedTimer t(r, st, CASTER_K_FINISH);
-    hipLaunchKernelGGL(k_finish, dim3(r->n_cu * 8), dim3(256), 0, st, L, r->acc, n, r->y0, r->y1);
+    hipLaunchKernelGGL(k_finish, dim3(r->n_cu * 8), dim3(256), 0, st, L, r->acc, n);
   }
   HIPCHECK(hipEventRecord(ln.finish_done, st));
   r->last_finish = ln.finish_done;
@@ -815,7 +826,15 @@ int caster_scene_load(const char* json_path, caster_scene** out) {
   if (!json_path || !out) return fail(CASTER_ERR_ARG, "caster_scene_load: null argument");
   caster_scene* s = new caster_scene();
   std::string err;
-  if (!load_scene(json_path, s->scene, err)) {
+  bool ok = false;
+  try {
+    ok = load_scene(json_path, s->scene, err);
+  } catch (const std::exception& e) {   // (a malformed file that asks for more memory than there is, and the like)
+    err = std::string("loading the scene failed: ") + e.what();
+  } catch (...) {
+    err = "loading the scene failed";
+  }
+  if (!ok) {
     delete s;
     return fail(CASTER_ERR_SCENE, err);
   }
@@ -835,7 +854,15 @@ int caster_scene_load_device(const char* json_path, int device_id, caster_scene*
     return fail(CASTER_ERR_DEVICE, "caster_scene_load_device: no such HIP device");
   caster_scene* s = new caster_scene();
   std::string err;
-  if (!load_scene(json_path, s->scene, err, gpu_builder, &device_id)) {
+  bool ok = false;
+  try {
+    ok = load_scene(json_path, s->scene, err, gpu_builder, &device_id);
+  } catch (const std::exception& e) {
+    err = std::string("loading the scene failed: ") + e.what();
+  } catch (...) {
+    err = "loading the scene failed";
+  }
+  if (!ok) {
     delete s;
     return fail(CASTER_ERR_SCENE, err);
   }
@@ -903,10 +930,45 @@ int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, cast
   return caster_begin_streams(s, device_id, iters_in_flight, 0, out);
 }
 
+int caster_set_row_stripes(caster_renderer* r, int y0, int y1, int rows, int stride) {
+  if (!r || y0 < 0 || y1 > r->S.height || y0 > y1 || rows < 1 || stride < rows)
+    return fail(CASTER_ERR_ARG, "caster_set_row_stripes: bad row set");
+  HIPCHECK(hipSetDevice(r->device));
+  int rc = sync_lanes(r);   // batches under way were laid out for the previous row set
+  if (rc) return rc;
+  DevScene& S = r->S;
+  S.row_y0 = y0; S.row_y1 = y1; S.row_rows = rows; S.row_stride = stride;
+  auto live = [&](int y) { return y >= y0 && y < y1 && (y - y0) % stride < rows; };
+  uint32_t n_rows = 0;
+  for (int y = 0; y < S.height; ++y) n_rows += live(y) ? 1u : 0u;
+  r->live_pixels = n_rows * (uint32_t)S.width;
+  const int all_tile_rows = (S.height + 7) / 8;
+  if (y0 % 8 == 0 && rows % 8 == 0 && stride % 8 == 0) {
+    // slabs of whole tile rows: only those are given path slots
+    S.tile_row0 = y0 / 8; S.tile_rows = rows / 8; S.tile_stride = stride / 8;
+    int n = 0;
+    for (int ty = 0; ty < all_tile_rows; ++ty) n += live(ty * 8) ? 1 : 0;
+    S.tiles_y = std::max(n, 1);
+  } else if (rows == stride && y0 % 8 == 0) {
+    // one band that starts on a tile row: the tile rows it touches
+    S.tile_row0 = y0 / 8; S.tile_rows = 1; S.tile_stride = 1;
+    S.tiles_y = std::max((y1 - y0 + 7) / 8, 1);
+  } else {
+    S.tile_row0 = 0; S.tile_rows = 1; S.tile_stride = 1;
+    S.tiles_y = all_tile_rows;
+  }
+  S.slots_per_iter = S.tiles_x * S.tiles_y * 64;
+  // the path pool was sized for iters_in_flight iterations of the whole image: a part of the image gets
+  // proportionally more iterations per batch, so that its batches keep their size in paths
+  long long fit = (long long)r->pool_slots / S.slots_per_iter;
+  if (r->S.integrator == IT_BDPT) fit = r->iters_in_flight;   // (its queues only serve the first-hit map)
+  r->batch_iters = (int)std::max<long long>(1, std::min<long long>(fit, 1024));
+  return CASTER_OK;
+}
+
 int caster_set_rows(caster_renderer* r, int y0, int y1) {
   if (!r || y0 < 0 || y1 > r->S.height || y0 > y1) return fail(CASTER_ERR_ARG, "caster_set_rows: bad range");
-  r->y0 = y0; r->y1 = y1;
-  return CASTER_OK;
+  return caster_set_row_stripes(r, y0, y1, 1, 1);
 }
 
 int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset) {
@@ -925,7 +987,7 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
     // one batch per stream: first what needs no host round trip, then the rest in batch order
     uint32_t heads = 0;
     for (; heads < n_lanes && done < n_iter; ++heads) {
-      uint32_t n = std::min<uint32_t>(n_iter - done, (uint32_t)r->iters_in_flight);
+      uint32_t n = std::min<uint32_t>(n_iter - done, (uint32_t)r->batch_iters);
       int rc = enqueue_batch(r, (r->next_lane + heads) % n_lanes, false, first_iter + done, n);
       if (rc) return rc;
       done += n;
@@ -937,7 +999,7 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
     r->next_lane = (r->next_lane + heads) % n_lanes;
   }
   r->iterations += n_iter;
-  r->samples += (uint64_t)r->S.width * (uint64_t)(r->y1 - r->y0) * n_iter;
+  r->samples += (uint64_t)r->live_pixels * n_iter;
   return CASTER_OK;
 }
 
@@ -1047,14 +1109,13 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   if (rc) return rc;
   Lane& ln = r->lanes[0];
   hipStream_t st = ln.stream;
-  LaunchCtx L = ctx_of(r, ln);
-  const uint32_t total = (uint32_t)r->S.slots_per_iter;
+  LaunchCtx L{r->S_full, ln.P, ln.stats};   // the map is of the whole image whatever rows the renderer traces
+  const uint32_t total = (uint32_t)r->S_full.slots_per_iter;
   if (r->S.integrator == IT_LT)  // the first surface each light path reaches
-    hipLaunchKernelGGL(k_generate_lt<false>, dim3(r->shade_grid), dim3(kWave), 0, st, L, ln.ext[0], iter, 1u, 0, r->S.height,
+    hipLaunchKernelGGL(k_generate_lt<false>, dim3(r->shade_grid), dim3(kWave), 0, st, L, ln.ext[0], iter, 1u,
                        (float*)nullptr, ln.aux, LtConn{});
   else
-    hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, st, L, ln.ext[0], iter, 1u,
-                       0, r->S.height);
+    hipLaunchKernelGGL(k_generate, dim3((total + kWave - 1) / kWave), dim3(kWave), 0, st, L, ln.ext[0], iter, 1u);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.ext[0].count, total);
   auto reset_work = [&]() {
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr,
@@ -1189,6 +1250,21 @@ int caster_get_stats(caster_renderer* r, caster_stats* out) {
     out->stack_overflow += st.stack_overflow;
   }
   out->samples = r->samples;
+  return CASTER_OK;
+}
+
+int caster_get_walk_counts(caster_renderer* r, uint64_t* out4) {
+  if (!r || !out4) return fail(CASTER_ERR_ARG, "caster_get_walk_counts: null argument");
+  HIPCHECK(hipSetDevice(r->device));
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  for (int i = 0; i < 4; ++i) out4[i] = 0;
+  for (Lane& ln : r->lanes) {
+    Stats st;
+    HIPCHECK(hipMemcpy(&st, ln.stats, sizeof(Stats), hipMemcpyDeviceToHost));
+    out4[0] += st.node_fetches[0]; out4[1] += st.prim_tests[0];
+    out4[2] += st.node_fetches[1]; out4[3] += st.prim_tests[1];
+  }
   return CASTER_OK;
 }
 

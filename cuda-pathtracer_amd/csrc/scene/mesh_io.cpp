@@ -180,8 +180,9 @@ bool load_ply(const std::string& path, RawMesh& m, std::string& err) {
     ls >> w;
     if (w == "format") { ls >> w; binary = (w == "binary_little_endian"); }
     else if (w == "element") {
-      std::string name; int cnt;
+      std::string name; int cnt = -1;
       ls >> name >> cnt;
+      if (ls.fail() || cnt < 0) { err = "PLY \"" + path + "\": bad element count"; return false; }
       if (name == "vertex") { nv = cnt; section = 1; }
       else if (name == "face") { nf = cnt; section = 2; }
       else section = 3;
@@ -203,8 +204,9 @@ bool load_ply(const std::string& path, RawMesh& m, std::string& err) {
   if (ix < 0 || iy < 0 || iz < 0 || inx < 0 || iny < 0 || inz < 0) {
     err = "PLY \"" + path + "\" needs x,y,z,nx,ny,nz"; return false;
   }
+  if (vprops.size() > 32) { err = "PLY \"" + path + "\" has more than 32 vertex properties"; return false; }
   size_t stride = vprops.size() * 4;
-  if (body + stride * (size_t)nv > data.size()) { err = "truncated PLY"; return false; }
+  if (body > data.size() || stride * (size_t)nv > data.size() - body) { err = "truncated PLY"; return false; }
   const char* p = data.data() + body;
   m.pos.resize(nv); m.nrm.resize(nv);
   if (iu >= 0 && iv >= 0) m.uv.resize(nv);

@@ -12,9 +12,11 @@ collective until the single film exchange at the end:
           summed onto rank 0 (``torch.distributed.reduce``, RCCL over xGMI on
           GPUs).  The sum differs from a one-GPU render only by fp32
           re-association across ranks.
-``tile``  every rank renders all iterations for its own band of scanlines;
-          the other rows of its film stay zero, so the same sum is an exact
-          gather: bit-identical to a one-GPU render.
+``tile``  every rank renders all iterations for its own scanlines -- slabs of
+          8 dealt round-robin over the ranks (``row_stripes``), so that every
+          rank sees a sample of the whole image, or one contiguous band
+          (``row_band``); the other rows of its film stay zero, so the same
+          sum is an exact gather: bit-identical to a one-GPU render.
 
 Nothing here touches a device: the functions take and return plain numbers and
 ``torch`` tensors, so the same code runs over ``gloo`` on CPUs in the tests.
@@ -48,6 +50,22 @@ def row_band(height, rank, world, align=8):
     lo = (units * rank) // world
     hi = (units * (rank + 1)) // world
     return min(lo * align, height), min(hi * align, height)
+
+
+def row_stripes(height, rank, world, slab=8):
+    """Interleaved scanline slabs of `rank`: (y0, y1, rows, stride) for caster_set_row_stripes, i.e. the
+    scanlines y0 <= y < y1 with (y - y0) % stride < rows.  Slab j (scanlines [j * slab, (j + 1) * slab)) goes
+    to rank j % world.  `slab` is a multiple of 8: the renderer generates camera rays in 8x8 pixel tiles, and
+    whole tile rows are what lets it give path slots to its own scanlines only."""
+    if world <= 0 or not (0 <= rank < world) or height < 0 or slab <= 0 or slab % 8:
+        raise ValueError("bad sharding arguments")
+    y0 = min(rank * slab, height)
+    return y0, height, slab, world * slab
+
+
+def stripe_rows(height, y0, y1, rows, stride):
+    """The scanlines of a row set, as a list (what the renderer traces for those four numbers)."""
+    return [y for y in range(max(y0, 0), min(y1, height)) if (y - y0) % stride < rows]
 
 
 def reduce_film(film, dist=None, dst=0):

@@ -87,6 +87,16 @@ int caster_begin_streams(const caster_scene* s, int device_id, int iters_in_flig
 /* Restricts this renderer to scanlines [y0, y1) of the image (tile sharding
    across GPUs).  Default is the whole image. */
 int caster_set_rows(caster_renderer* r, int y0, int y1);
+/* Restricts this renderer to the scanlines y0 <= y < y1 with (y - y0) % stride < rows:
+   slabs of `rows` scanlines every `stride` (interleaved tile sharding: GPU k of G
+   takes (8k, height, 8, 8G), so that every GPU sees a sample of the whole image and
+   none is left with its dearest band).  The reference launches one thread per pixel
+   of the whole image (pathtracer.cu:2693-2703); a sample depends on its pixel and
+   iteration only (pathtracer.cu:881), so any subset of scanlines renders the same
+   values.  Where y0, rows and stride are multiples of 8 only those scanlines take
+   path slots, and a batch holds proportionally more iterations.  Waits for work
+   under way.  (1 <= rows <= stride.) */
+int caster_set_row_stripes(caster_renderer* r, int y0, int y1, int rows, int stride);
 
 /* Replaces n_iter calls of Render (pathtracer.cu:2691-2742) for iterations
    first_iter .. first_iter+n_iter-1 (the reference counts from 1,
@@ -95,8 +105,13 @@ int caster_set_rows(caster_renderer* r, int y0, int y1);
    `reset`, pathtracer.cu:2507).  Returns after the GPU has finished. */
 int caster_render(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset);
 
-/* Same, but only enqueues the work on the renderer's streams (no host
-   synchronisation); pair with caster_sync. */
+/* Same, but only enqueues the work on the renderer's streams; pair with
+   caster_sync.  For ao, pt and bdpt the call does not wait for the GPU.  For vpt
+   and lt the number of rounds of a batch depends on the data (a boundary crossing
+   consumes no bounce, pathtracer.cu:1106-1113), so after the first maxDepth
+   rounds of every stream's batch have been enqueued the call waits for each
+   batch in turn to ask whether rays are left: it returns once the last batch
+   of the call has been enqueued in full, not before. */
 int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset);
 int caster_sync(caster_renderer* r);
 
@@ -169,6 +184,12 @@ int caster_set_profiling(caster_renderer* r, int enable);
 int caster_get_kernel_times(caster_renderer* r, caster_kernel_times* out);
 
 int caster_get_stats(caster_renderer* r, caster_stats* out);
+/* What the traversal kernel itself fetched since caster_begin / the last reset (measurement aid,
+   no counterpart in the reference): out4[0] = 4-wide node records read from memory by closest-hit
+   rays (extension, probe, transmittance), out4[1] = primitive records they tested, out4[2] and
+   out4[3] the same for any-hit (shadow) rays.  The top levels of the tree are served from LDS
+   and not counted; walks done in place by the splatting integrators are not counted either. */
+int caster_get_walk_counts(caster_renderer* r, uint64_t* out4);
 int caster_reset_stats(caster_renderer* r);
 uint32_t caster_iterations(const caster_renderer* r);
 /* Iterations per batch of paths this renderer was given (the default depends on the

@@ -26,6 +26,11 @@ def main():
         for first, n in sh.spp_blocks(1, spp, 2, rank, world):
             o.render(first, n, 1, acc=acc)
             n_mine += n
+    elif mode == "stripes":
+        rows = sh.stripe_rows(o.height, *sh.row_stripes(o.height, rank, world))
+        for y in rows[::8]:   # slabs of 8 scanlines (the last may be shorter)
+            o.render(1, spp, 1, acc=acc, rows=(y, min(y + 8, o.height)))
+        n_mine = spp if rank == 0 else 0
     else:
         y0, y1 = sh.row_band(o.height, rank, world)
         o.render(1, spp, 1, acc=acc, rows=(y0, y1))

@@ -135,6 +135,14 @@ def test_sharding_plans(caster):
         for a, b in zip(rows, rows[1:]):
             assert a[1] == b[0] and a[1] % 8 == 0             # contiguous, 8-aligned edges
     assert sh.row_band(45, 1, 2) == (24, 45)
+    # interleaved slabs: every scanline exactly once, slab j with rank j % world
+    for height in (1080, 45, 7):
+        for world in (1, 2, 3, 8):
+            rows = [sh.stripe_rows(height, *sh.row_stripes(height, r, world)) for r in range(world)]
+            assert sorted(y for part in rows for y in part) == list(range(height))
+            for r, part in enumerate(rows):
+                assert all((y // 8) % world == r for y in part)
+    assert sh.row_stripes(1080, 3, 8) == (24, 1080, 8, 64)
     with pytest.raises(ValueError):
         sh.spp_blocks(1, 4, 0, 0, 1)
 
@@ -671,3 +679,27 @@ def test_tga_16_bit_and_refusals(caster, tmp_path):
         (tmp_path / "t.tga").write_bytes(blob)
         with pytest.raises(caster.CasterError, match=needle):
             caster.Scene(write_scene(tmp_path, doc, [("q.obj", QUAD)]))
+
+
+@pytest.mark.parametrize("header, needle", [
+    (b"element vertex -3\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\n"
+     b"property float nz\nelement face 1\n", "bad element count"),
+    (b"element vertex many\nproperty float x\n", "bad element count"),
+    (b"element vertex 3\n" + b"".join(b"property float p%d\n" % i for i in range(40)) +
+     b"property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+     b"element face 1\n", "more than 32 vertex properties"),
+    (b"element vertex 2000000000\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\n"
+     b"property float ny\nproperty float nz\nelement face 1\n", "truncated"),
+])
+def test_ply_headers_that_lie_are_refused(caster, tmp_path, header, needle):
+    """A PLY header's counts are checked before anything is sized or indexed by them; the loader answers with
+    CASTER_ERR_SCENE (no exception crosses the C boundary)."""
+    import json
+    (tmp_path / "m.ply").write_bytes(b"ply\nformat binary_little_endian 1.0\n" + header +
+                                     b"property list uchar int vertex_indices\nend_header\n" + bytes(200))
+    doc = {"material": [{"name": "w", "bsdf": "lambertian", "diffuse": [0.5, 0.5, 0.5]}],
+           "scene": [{"mesh": "m.ply", "material": "w"}], "camera": {"position": [0, 0, 3], "lookat": [0, 0, 0]}}
+    (tmp_path / "scene.json").write_text(json.dumps(doc))
+    with pytest.raises(caster.CasterError) as e:
+        caster.Scene(str(tmp_path / "scene.json"))
+    assert e.value.code == 2 and needle in str(e.value)

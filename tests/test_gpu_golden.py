@@ -117,6 +117,58 @@ def test_tile_and_spp_sharding_on_one_gpu(caster):
     assert rel_rmse(sppsum, want) <= 1e-5
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_interleaved_stripes_on_one_gpu(caster, world):
+    """Slabs of 8 scanlines dealt round-robin over `world` renderers: each traces its own scanlines only (and
+    gives its path slots to them only, so a batch holds `world` times the iterations), the films add up to the
+    one-renderer film bit for bit.  A row set that is not made of whole tile rows goes the general way."""
+    sh = importlib.import_module("cuda-pathtracer_amd.sharding")
+    sc = caster.Scene(os.path.join(GOLD, "scenes", "stairs_pt", "scene.json"))
+    spp = 8
+    one = caster.Renderer(sc, 0, 2)
+    one.render(1, spp, True)
+    want = one.read_film(2)
+    one.close()
+    total = np.zeros_like(want)
+    samples = 0
+    for rank in range(world):
+        r = caster.Renderer(sc, 0, 2, 2)
+        plan = sh.row_stripes(sc.height, rank, world)
+        r.set_row_stripes(*plan)
+        r.render(1, spp, True)
+        part = r.read_film(2)
+        mine = sh.stripe_rows(sc.height, *plan)
+        others = [y for y in range(sc.height) if y not in mine]
+        assert part[mine].any() and not part[others].any()
+        np.testing.assert_array_equal(r.primary_ids(1), one_ids(caster, sc))   # the first-hit map stays that of the whole image
+        samples += r.stats()["samples"]
+        total += part
+        r.close()
+    assert samples == sc.width * sc.height * spp
+    np.testing.assert_array_equal(total, want)
+    # slabs of 3 scanlines every 7, from scanline 5 on: no whole tile rows
+    r = caster.Renderer(sc, 0, 2)
+    r.set_row_stripes(5, sc.height - 2, 3, 7)
+    r.render(1, spp, True)
+    part = r.read_film(2)
+    r.close()
+    mine = sh.stripe_rows(sc.height, 5, sc.height - 2, 3, 7)
+    others = [y for y in range(sc.height) if y not in mine]
+    np.testing.assert_array_equal(part[mine], want[mine])
+    assert not part[others].any()
+
+
+_IDS = {}
+
+
+def one_ids(caster, sc):
+    if "ids" not in _IDS:
+        r = caster.Renderer(sc, 0, 1)
+        _IDS["ids"] = r.primary_ids(1)
+        r.close()
+    return _IDS["ids"]
+
+
 def test_reference_style_interface(caster):
     """BeginRender / Render / EndRender and the CudaRender mirror: iteration i's output is the
     tonemapped running mean, as Output() writes it."""

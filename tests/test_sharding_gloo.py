@@ -1,5 +1,5 @@
 """The N > 1 path on CPUs: two processes over gloo split one image by iterations
-(spp) and by scanline bands (tile) with the product's sharding plans and film
+(spp), by scanline bands (tile) and by interleaved slabs of scanlines (stripes) with the product's sharding plans and film
 reduce; the CPU oracle stands in for the GPU renderer (no GPU here).  Tile
 sharding must be bit-identical to one process, spp sharding within fp32
 re-association (relRMSE <= 1e-5)."""
@@ -17,12 +17,12 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 WORKER = os.path.join(ROOT, "tests", "sharding_worker.py")
 
 
-@pytest.mark.parametrize("mode", ["spp", "tile"])
+@pytest.mark.parametrize("mode", ["spp", "tile", "stripes"])
 def test_two_ranks_match_one(tmp_path, mode):
     scene = os.path.join(GOLD, "scenes", "cornell_pt", "scene.json")
     spp = 6
     out = str(tmp_path / "film.npy")
-    port = 29500 + (os.getpid() % 2000) + (0 if mode == "spp" else 1)
+    port = 29500 + (os.getpid() % 2000) + ["spp", "tile", "stripes"].index(mode)
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -31,7 +31,7 @@ def test_two_ranks_match_one(tmp_path, mode):
         assert p.wait(timeout=240) == 0
     got = np.load(out)
     want = ol.Oracle(scene).render(1, spp, 2)
-    if mode == "tile":
+    if mode != "spp":
         np.testing.assert_array_equal(got, want)
     else:
         d = (got - want) / (np.abs(want) + 1e-2)
