@@ -59,7 +59,7 @@ _lib = None
 
 # every symbol include/caster.h declares
 EXPORTS = [
-    "caster_scene_load", "caster_scene_load_device", "caster_scene_get_bvh", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams",
+    "caster_scene_load", "caster_scene_load_device", "caster_scene_get_bvh", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams", "caster_begin_multi",
     "caster_set_rows", "caster_set_row_stripes",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
     "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_trace_rays_static", "caster_get_stats", "caster_get_walk_counts", "caster_reset_stats",
@@ -106,6 +106,7 @@ def lib():
         L.caster_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
         L.caster_begin.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
         L.caster_begin_streams.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.caster_begin_multi.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.caster_set_rows.argtypes = [vp, C.c_int, C.c_int]
         L.caster_set_row_stripes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.caster_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
@@ -183,9 +184,16 @@ class Scene:
 class Renderer:
     """Device-side render state for one scene on one GPU."""
 
-    def __init__(self, scene, device=0, iters_in_flight=0, n_streams=0):
+    def __init__(self, scene, device=0, iters_in_flight=0, n_streams=0, shard="tile"):
+        """`device`: a HIP device index, or a list of them for one renderer over several GPUs
+        (caster_begin_multi; `shard` = "tile" or "spp" says how the image is dealt to them)."""
         h = C.c_void_p()
-        _check(lib().caster_begin_streams(scene._h, int(device), int(iters_in_flight), int(n_streams), C.byref(h)))
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*[int(d) for d in device])
+            _check(lib().caster_begin_multi(scene._h, ids, len(device), int(iters_in_flight), int(n_streams),
+                                            {"tile": 0, "spp": 1}[shard], C.byref(h)))
+        else:
+            _check(lib().caster_begin_streams(scene._h, int(device), int(iters_in_flight), int(n_streams), C.byref(h)))
         self._h = h
         self.width, self.height = scene.width, scene.height
         self.integrator = scene.integrator

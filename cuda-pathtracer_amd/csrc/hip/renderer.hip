@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/caster.h"
@@ -317,6 +318,14 @@ struct Lane {
 };
 
 struct caster_renderer {
+  // A renderer made by caster_begin_multi owns one renderer per device and nothing else: every call on it is
+  // dealt to them (each from a host thread of its own, with that device current) and their films meet on
+  // the first one's device when the film is read.
+  std::vector<caster_renderer*> parts;
+  int shard_mode = CASTER_SHARD_TILE;
+  float* group_sum = nullptr;    // on parts[0]'s device: the films of all parts added up
+  float* group_peer = nullptr;   // on parts[0]'s device: one part's film on its way in
+  std::string part_error;        // what the last failing part reported
   int device = 0;
   std::vector<Lane> lanes;
   uint32_t next_lane = 0;
@@ -818,6 +827,16 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
 
 }  // namespace caster
 
+__global__ void k_film_add(float* acc, const float* add, uint32_t n) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc[i] += add[i];
+}
+
+namespace caster {
+static int multi_render_async(caster_renderer* g, uint32_t first_iter, uint32_t n_iter, int reset);
+static int multi_read_film_device(caster_renderer* g, float* dev, int mode);
+template <class Fn> static int for_each_part(caster_renderer* g, Fn fn);
+}
+
 extern "C" {
 
 const char* caster_last_error(void) { return g_last_error.c_str(); }
@@ -901,6 +920,11 @@ int caster_scene_get_info(const caster_scene* s, caster_scene_info* o) {
 
 void caster_end(caster_renderer* r) {
   if (!r) return;
+  if (!r->parts.empty()) {   // (the group's own buffers are among its first part's allocations)
+    for (caster_renderer* p : r->parts) caster_end(p);
+    delete r;
+    return;
+  }
   (void)hipSetDevice(r->device);
   for (Lane& ln : r->lanes) {
     if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
@@ -931,6 +955,7 @@ int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, cast
 }
 
 int caster_set_row_stripes(caster_renderer* r, int y0, int y1, int rows, int stride) {
+  if (r && !r->parts.empty()) return fail(CASTER_ERR_ARG, "caster_set_row_stripes: a multi-device renderer deals the scanlines itself");
   if (!r || y0 < 0 || y1 > r->S.height || y0 > y1 || rows < 1 || stride < rows)
     return fail(CASTER_ERR_ARG, "caster_set_row_stripes: bad row set");
   HIPCHECK(hipSetDevice(r->device));
@@ -973,6 +998,7 @@ int caster_set_rows(caster_renderer* r, int y0, int y1) {
 
 int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset) {
   if (!r) return fail(CASTER_ERR_ARG, "caster_render: null renderer");
+  if (!r->parts.empty()) return multi_render_async(r, first_iter, n_iter, reset);
   HIPCHECK(hipSetDevice(r->device));
   if (reset) {
     int rc = sync_lanes(r);
@@ -1005,6 +1031,7 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
 
 int caster_sync(caster_renderer* r) {
   if (!r) return fail(CASTER_ERR_ARG, "caster_sync: null renderer");
+  if (!r->parts.empty()) return for_each_part(r, [&](int i) { return caster_sync(r->parts[(size_t)i]); });
   HIPCHECK(hipSetDevice(r->device));
   int rc = sync_lanes(r);
   if (rc) return rc;
@@ -1014,6 +1041,7 @@ int caster_sync(caster_renderer* r) {
 
 int caster_set_profiling(caster_renderer* r, int enable) {
   if (!r) return fail(CASTER_ERR_ARG, "caster_set_profiling: null renderer");
+  if (!r->parts.empty()) return for_each_part(r, [&](int i) { return caster_set_profiling(r->parts[(size_t)i], enable); });
   int rc = caster_sync(r);
   if (rc) return rc;
   r->profiling = enable != 0;
@@ -1023,6 +1051,16 @@ int caster_set_profiling(caster_renderer* r, int enable) {
 
 int caster_get_kernel_times(caster_renderer* r, caster_kernel_times* out) {
   if (!r || !out) return fail(CASTER_ERR_ARG, "caster_get_kernel_times: null argument");
+  if (!r->parts.empty()) {   // summed over the devices
+    for (int k = 0; k < CASTER_N_KERNEL_CLASSES; ++k) { out->ms[k] = 0; out->launches[k] = 0; }
+    for (caster_renderer* p : r->parts) {
+      caster_kernel_times t;
+      int rc = caster_get_kernel_times(p, &t);
+      if (rc) return rc;
+      for (int k = 0; k < CASTER_N_KERNEL_CLASSES; ++k) { out->ms[k] += t.ms[k]; out->launches[k] += t.launches[k]; }
+    }
+    return CASTER_OK;
+  }
   int rc = caster_sync(r);
   if (rc) return rc;
   for (int i = 0; i < CASTER_N_KERNEL_CLASSES; ++i) { out->ms[i] = r->class_ms[i]; out->launches[i] = r->class_launches[i]; }
@@ -1043,6 +1081,7 @@ int caster_render(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int 
 
 int caster_read_film_device(caster_renderer* r, float* dev, int mode) {
   if (!r || !dev || mode < 0 || mode > 2) return fail(CASTER_ERR_ARG, "caster_read_film: bad argument");
+  if (!r->parts.empty()) return multi_read_film_device(r, dev, mode);
   HIPCHECK(hipSetDevice(r->device));
   int rc = sync_lanes(r);
   if (rc) return rc;
@@ -1058,9 +1097,10 @@ int caster_read_film_device(caster_renderer* r, float* dev, int mode) {
 
 int caster_read_film(caster_renderer* r, float* rgb, int mode) {
   if (!r || !rgb) return fail(CASTER_ERR_ARG, "caster_read_film: null argument");
-  int rc = caster_read_film_device(r, r->film_tmp, mode);
+  float* tmp = r->parts.empty() ? r->film_tmp : r->group_sum;   // (a group resolves its summed film in place)
+  int rc = caster_read_film_device(r, tmp, mode);
   if (rc) return rc;
-  HIPCHECK(hipMemcpy(rgb, r->film_tmp, (size_t)r->S.width * r->S.height * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(rgb, tmp, (size_t)r->S.width * r->S.height * 3 * sizeof(float), hipMemcpyDeviceToHost));
   return CASTER_OK;
 }
 
@@ -1084,12 +1124,14 @@ int caster_save_image(caster_renderer* r, const char* path, int mode) {
   return caster_write_image(path, r->S.width, r->S.height, host.data());
 }
 
-__global__ void k_film_add(float* acc, const float* add, uint32_t n) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc[i] += add[i];
-}
 
 int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t n_iters) {
   if (!r || !sum_device) return fail(CASTER_ERR_ARG, "caster_film_add_device: null argument");
+  if (!r->parts.empty()) {   // merged into the first device's film; the iterations count for the whole group
+    int rc = caster_film_add_device(r->parts[0], sum_device, 0);
+    if (!rc) r->iterations += n_iters;
+    return rc;
+  }
   HIPCHECK(hipSetDevice(r->device));
   int rc = sync_lanes(r);
   if (rc) return rc;
@@ -1104,6 +1146,7 @@ int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t
 
 int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   if (!r || !ids) return fail(CASTER_ERR_ARG, "caster_primary_ids: null argument");
+  if (!r->parts.empty()) return caster_primary_ids(r->parts[0], iter, ids);
   HIPCHECK(hipSetDevice(r->device));
   int rc = sync_lanes(r);
   if (rc) return rc;
@@ -1136,6 +1179,7 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
 int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, const float* dirs, const float* tmax,
                       int32_t* prim, float* t) {
   if (!r || !origins || !dirs || !tmax || !prim || !t) return fail(CASTER_ERR_ARG, "caster_trace_rays: null argument");
+  if (!r->parts.empty()) return caster_trace_rays(r->parts[0], n, origins, dirs, tmax, prim, t);
   const uint32_t cap = r->S.integrator == IT_BDPT ? (uint32_t)r->S.slots_per_iter : r->pool_slots;
   if (n > cap) return fail(CASTER_ERR_ARG, "caster_trace_rays: more rays than the renderer has path slots");
   if (n == 0) return CASTER_OK;
@@ -1199,6 +1243,7 @@ int caster_trace_rays_static(caster_renderer* r, uint32_t n, const float* origin
                              const float* tmax_dev, int32_t* prim_dev, float* t_dev) {
   if (!r || !origins_dev || !dirs_dev || !tmax_dev || !prim_dev || !t_dev)
     return fail(CASTER_ERR_ARG, "caster_trace_rays_static: null argument");
+  if (!r->parts.empty()) return caster_trace_rays_static(r->parts[0], n, origins_dev, dirs_dev, tmax_dev, prim_dev, t_dev);
   if (n > kStaticMaxRays)
     return fail(CASTER_ERR_ARG, "caster_trace_rays_static: more than CASTER_STATIC_MAX_RAYS (" + std::to_string(kStaticMaxRays) +
                                     ") rays in one call");
@@ -1236,6 +1281,17 @@ int caster_trace_rays_static(caster_renderer* r, uint32_t n, const float* origin
 
 int caster_get_stats(caster_renderer* r, caster_stats* out) {
   if (!r || !out) return fail(CASTER_ERR_ARG, "caster_get_stats: null argument");
+  if (!r->parts.empty()) {   // summed over the devices
+    memset(out, 0, sizeof(*out));
+    for (caster_renderer* p : r->parts) {
+      caster_stats st;
+      int rc = caster_get_stats(p, &st);
+      if (rc) return rc;
+      for (int i = 0; i < 4; ++i) out->rays[i] += st.rays[i];
+      out->samples += st.samples; out->invalid += st.invalid; out->stack_overflow += st.stack_overflow;
+    }
+    return CASTER_OK;
+  }
   HIPCHECK(hipSetDevice(r->device));
   int rc = sync_lanes(r);
   if (rc) return rc;
@@ -1255,6 +1311,16 @@ int caster_get_stats(caster_renderer* r, caster_stats* out) {
 
 int caster_get_walk_counts(caster_renderer* r, uint64_t* out4) {
   if (!r || !out4) return fail(CASTER_ERR_ARG, "caster_get_walk_counts: null argument");
+  if (!r->parts.empty()) {
+    for (int i = 0; i < 4; ++i) out4[i] = 0;
+    for (caster_renderer* p : r->parts) {
+      uint64_t c[4];
+      int rc = caster_get_walk_counts(p, c);
+      if (rc) return rc;
+      for (int i = 0; i < 4; ++i) out4[i] += c[i];
+    }
+    return CASTER_OK;
+  }
   HIPCHECK(hipSetDevice(r->device));
   int rc = sync_lanes(r);
   if (rc) return rc;
@@ -1270,6 +1336,7 @@ int caster_get_walk_counts(caster_renderer* r, uint64_t* out4) {
 
 int caster_reset_stats(caster_renderer* r) {
   if (!r) return fail(CASTER_ERR_ARG, "caster_reset_stats: null renderer");
+  if (!r->parts.empty()) return for_each_part(r, [&](int i) { return caster_reset_stats(r->parts[(size_t)i]); });
   HIPCHECK(hipSetDevice(r->device));
   int rc = sync_lanes(r);
   if (rc) return rc;
@@ -1293,3 +1360,126 @@ int caster_debug_walk_stats(unsigned long long* out16) {
 #endif
 
 }  // extern "C"
+
+// ---- several devices behind one handle -------------------------------------------------------------------
+namespace caster {
+
+// Runs fn(part index) for every part of the group, each on a host thread of its own (HIP's current device is
+// per thread, and a call that waits for its device -- caster_sync, the data-dependent rounds of vpt and lt --
+// must not hold up the other devices); returns the first failure.
+template <class Fn>
+static int for_each_part(caster_renderer* g, Fn fn) {
+  const size_t n = g->parts.size();
+  std::vector<int> rc(n, CASTER_OK);
+  std::vector<std::string> msg(n);
+  std::vector<std::thread> th;
+  th.reserve(n);
+  for (size_t i = 0; i < n; ++i)
+    th.emplace_back([&, i]() {
+      rc[i] = fn((int)i);
+      if (rc[i]) msg[i] = g_last_error;   // (the message is the worker thread's)
+    });
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < n; ++i)
+    if (rc[i]) return fail(rc[i], "device " + std::to_string(g->parts[i]->device) + ": " + msg[i]);
+  return CASTER_OK;
+}
+
+// Iterations [first, first + n) as part `k` of `world` renders them under spp sharding: blocks of `block`
+// iterations dealt round-robin, as sharding.spp_blocks deals them to ranks.
+static void spp_blocks_of(uint32_t first, uint32_t n, uint32_t block, int k, int world, std::vector<std::pair<uint32_t, uint32_t>>& out) {
+  uint32_t it = first, end = first + n;
+  for (uint32_t b = 0; it < end; ++b) {
+    uint32_t m = std::min(block, end - it);
+    if ((int)(b % (uint32_t)world) == k) out.push_back({it, m});
+    it += m;
+  }
+}
+
+}  // namespace caster
+
+extern "C" {
+
+int caster_begin_multi(const caster_scene* s, const int* device_ids, int n_dev, int iters_in_flight, int n_streams, int shard_mode,
+                       caster_renderer** out) {
+  if (!s || !device_ids || !out || n_dev < 1 || n_dev > 64 || (shard_mode != CASTER_SHARD_TILE && shard_mode != CASTER_SHARD_SPP))
+    return fail(CASTER_ERR_ARG, "caster_begin_multi: bad argument");
+  caster_renderer* g = new caster_renderer();
+  g->shard_mode = shard_mode;
+  g->parts.assign((size_t)n_dev, nullptr);
+  int rc = for_each_part(g, [&](int i) { return caster_begin_streams(s, device_ids[i], iters_in_flight, n_streams, &g->parts[(size_t)i]); });
+  if (!rc && shard_mode == CASTER_SHARD_TILE) {
+    // slabs of 8 scanlines dealt round-robin: part k of G traces the scanlines y >= 8k with (y - 8k) % 8G < 8
+    const int h = s->scene.height;
+    rc = for_each_part(g, [&](int i) { return caster_set_row_stripes(g->parts[(size_t)i], std::min(8 * i, h), h, 8, 8 * n_dev); });
+  }
+  if (!rc) {
+    caster_renderer* p0 = g->parts[0];
+    g->device = p0->device;
+    g->S = p0->S_full;
+    g->iters_in_flight = p0->iters_in_flight;
+    if (hipSetDevice(p0->device) != hipSuccess) rc = fail(CASTER_ERR_DEVICE, "caster_begin_multi: hipSetDevice failed");
+    const size_t n = (size_t)g->S.width * g->S.height * 3;
+    if (!rc) rc = dev_alloc(p0, &g->group_sum, n);
+    if (!rc) rc = dev_alloc(p0, &g->group_peer, n);
+  }
+  if (rc) {
+    std::string keep = g_last_error;
+    caster_end(g);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = g;
+  return CASTER_OK;
+}
+
+}  // extern "C"
+
+namespace caster {
+
+static int multi_render_async(caster_renderer* g, uint32_t first_iter, uint32_t n_iter, int reset) {
+  const int world = (int)g->parts.size();
+  int rc = for_each_part(g, [&](int i) {
+    caster_renderer* p = g->parts[(size_t)i];
+    if (g->shard_mode == CASTER_SHARD_TILE) return caster_render_async(p, first_iter, n_iter, reset);
+    std::vector<std::pair<uint32_t, uint32_t>> blocks;
+    spp_blocks_of(first_iter, n_iter, (uint32_t)std::max(p->batch_iters, 1), i, world, blocks);
+    if (blocks.empty()) return reset ? caster_render_async(p, first_iter, 0, 1) : (int)CASTER_OK;
+    int r1 = CASTER_OK;
+    for (size_t b = 0; b < blocks.size() && !r1; ++b) r1 = caster_render_async(p, blocks[b].first, blocks[b].second, b == 0 ? reset : 0);
+    return r1;
+  });
+  if (rc) return rc;
+  if (reset) g->iterations = 0;
+  g->iterations += n_iter;
+  return CASTER_OK;
+}
+
+// The films of all parts, added up on the first part's device (disjoint scanlines under tile sharding: an
+// exact gather; disjoint iterations under spp sharding: a sum), then resolved as one film.
+static int multi_read_film_device(caster_renderer* g, float* dev, int mode) {
+  caster_renderer* p0 = g->parts[0];
+  const size_t n = (size_t)g->S.width * g->S.height * 3;
+  int rc = for_each_part(g, [&](int i) {
+    caster_renderer* p = g->parts[(size_t)i];
+    return caster_read_film_device(p, i == 0 ? g->group_sum : p->film_tmp, 2);   // the raw sums
+  });
+  if (rc) return rc;
+  HIPCHECK(hipSetDevice(p0->device));
+  hipStream_t st = p0->lanes[0].stream;
+  for (size_t i = 1; i < g->parts.size(); ++i) {
+    caster_renderer* p = g->parts[i];
+    HIPCHECK(hipMemcpyPeer(g->group_peer, p0->device, p->film_tmp, p->device, n * sizeof(float)));
+    hipLaunchKernelGGL(k_film_add, dim3(p0->n_cu * 4), dim3(256), 0, st, g->group_sum, (const float*)g->group_peer, (uint32_t)n);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+  }
+  float div = mode == 2 ? 1.f : (float)(g->iterations ? g->iterations : 1u);
+  hipLaunchKernelGGL(k_resolve_film, dim3(p0->n_cu * 4), dim3(256), 0, st, (const float*)g->group_sum, dev, (uint32_t)(n / 3), div,
+                     mode == 1 ? 1 : 0, g->S.cam.filmic);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize(st));
+  return CASTER_OK;
+}
+
+}  // namespace caster

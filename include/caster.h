@@ -84,6 +84,25 @@ int caster_begin(const caster_scene* s, int device_id, int iters_in_flight, cast
 int caster_begin_streams(const caster_scene* s, int device_id, int iters_in_flight, int n_streams,
                          caster_renderer** out);
 
+/* BeginRender for several GPUs behind one handle.  The reference is single-GPU
+   (one process, the default stream, no peer access anywhere in tracer/); a sample
+   depends on its pixel and iteration only (pathtracer.cu:881), so the image
+   shards with no exchange until the film is read.  The scene is uploaded to
+   every device of `device_ids` (a device may be named more than once: that many
+   renderers then share it).  shard_mode CASTER_SHARD_TILE deals slabs of 8
+   scanlines round-robin over the devices (every device renders every iteration
+   of its own scanlines: the film is bit-identical to one device's);
+   CASTER_SHARD_SPP deals blocks of iterations round-robin (every device renders
+   the whole frame; the films differ from one device's by fp32 re-association).
+   Every call on the handle drives all devices at once, each from a host thread
+   of its own; caster_read_film / caster_read_film_device copy the other devices'
+   films to the first device (hipMemcpyPeer) and add them up there.  The parity
+   hooks (caster_primary_ids, caster_trace_rays*) run on the first device;
+   caster_set_rows / caster_set_row_stripes are refused. */
+enum { CASTER_SHARD_TILE = 0, CASTER_SHARD_SPP = 1 };
+int caster_begin_multi(const caster_scene* s, const int* device_ids, int n_dev, int iters_in_flight, int n_streams,
+                       int shard_mode, caster_renderer** out);
+
 /* Restricts this renderer to scanlines [y0, y1) of the image (tile sharding
    across GPUs).  Default is the whole image. */
 int caster_set_rows(caster_renderer* r, int y0, int y1);

@@ -312,3 +312,45 @@ def test_render_tool_previews_and_ranks(tmp_path):
     np.testing.assert_array_equal(_read_pfm(outs["preview"]), plain)
     for name in ("ranks", "tiles"):
         np.testing.assert_allclose(_read_pfm(outs[name]), plain, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("key", ["stairs_pt", "cornell_vpt"])
+def test_several_devices_behind_one_handle(caster, key):
+    """caster_begin_multi with the device list [0, 0, 0] (three renderers sharing the one GPU of the test box):
+    tile sharding gives the one-device film bit for bit, spp sharding the same film up to fp32 re-association;
+    statistics and iteration counts are those of the whole job."""
+    sc = caster.Scene(os.path.join(GOLD, "scenes", key, "scene.json"))
+    spp = 12
+    one = caster.Renderer(sc, 0, 2)
+    one.render(1, spp, True)
+    want = one.read_film(2)
+    want_mean, want_tone = one.read_film(0), one.read_film(1)
+    st1 = one.stats()
+    ids = one.primary_ids(1)
+    one.close()
+    g = caster.Renderer(sc, [0, 0, 0], 2, 2, shard="tile")
+    for _ in range(2):             # a second render with reset gives the same film again
+        g.reset_stats()
+        g.render(1, spp, True)
+        np.testing.assert_array_equal(g.read_film(2), want)
+    np.testing.assert_array_equal(g.read_film(0), want_mean)
+    np.testing.assert_array_equal(g.read_film(1), want_tone)
+    st = g.stats()
+    assert g.iterations == spp and st["samples"] == st1["samples"] and st["rays"][0] == st1["rays"][0]
+    assert st["stack_overflow"] == 0
+    np.testing.assert_array_equal(g.primary_ids(1), ids)
+    with pytest.raises(caster.CasterError):
+        g.set_rows(0, 8)
+    # rendering on: iterations spp+1 .. spp+4 accumulate onto the same film
+    g.render(spp + 1, 4, False)
+    one = caster.Renderer(sc, 0, 2)
+    one.render(1, spp + 4, True)
+    np.testing.assert_array_equal(g.read_film(2), one.read_film(2))
+    one.close()
+    g.close()
+    g = caster.Renderer(sc, [0, 0], 2, 2, shard="spp")
+    g.render(1, spp, True)
+    got = g.read_film(2)
+    assert g.iterations == spp and g.stats()["samples"] == st1["samples"]
+    g.close()
+    assert rel_rmse(got, want) <= 1e-5
