@@ -62,7 +62,7 @@ EXPORTS = [
     "caster_scene_load", "caster_scene_load_device", "caster_scene_get_bvh", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams", "caster_begin_multi",
     "caster_set_rows", "caster_set_row_stripes",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
-    "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_trace_rays_static", "caster_get_stats", "caster_get_walk_counts", "caster_reset_stats",
+    "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_trace_rays_static", "caster_eval_function", "caster_get_stats", "caster_get_walk_counts", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
     "caster_write_image", "caster_save_image", "caster_iters_in_flight",
 ]
@@ -121,6 +121,7 @@ def lib():
         L.caster_trace_rays.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.caster_trace_rays_static.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp]
+        L.caster_eval_function.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.caster_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.caster_get_walk_counts.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.caster_reset_stats.argtypes = [vp]
@@ -252,6 +253,18 @@ class Renderer:
         """trace_rays on DEVICE arrays of the caller's (addresses), through the entry point that allocates nothing."""
         _check(lib().caster_trace_rays_static(self._h, int(n), *[C.c_void_p(p) for p in (origins_ptr, dirs_ptr, tmax_ptr,
                                                                                      prim_ptr, t_ptr)]))
+
+    FUNCTIONS = {"sample_bsdf": (0, 16, 7), "eval_bsdf": (1, 16, 4), "sample_light": (2, 6, 11), "camera_ray": (3, 3, 6),
+                 "hit_record": (4, 8, 15)}
+
+    def eval_function(self, name, rows):
+        """Runs device function `name` on the (n, width) float32 rows (integers as bit patterns: see include/caster.h)."""
+        fn, w_in, w_out = self.FUNCTIONS[name]
+        a = np.ascontiguousarray(rows, np.float32).reshape(-1, w_in)
+        out = np.empty((len(a), w_out), np.float32)
+        fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        _check(lib().caster_eval_function(self._h, fn, len(a), fp(a), fp(out)))
+        return out
 
     def stats(self):
         st = Stats()

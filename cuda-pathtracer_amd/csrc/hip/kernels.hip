@@ -29,3 +29,4 @@
 #include "kernels/bdpt.h"
 #include "kernels/volpath_queues.h"
 #include "kernels/film.h"
+#include "kernels/hooks.h"

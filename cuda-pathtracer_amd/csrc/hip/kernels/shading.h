@@ -197,6 +197,24 @@ __device__ inline int pick_light(const DevScene& S, float u, float& pdf) {
   pdf = uniform_load(S.light_cdf + last + 1) - uniform_load(S.light_cdf + last);
   return last;
 }
+// Area::SampleLight (area.h:12-17) with Triangle::SampleShape (Triangle.h:146-155): a uniform point on emissive
+// triangle `idx` as seen from `pos`; one-sided, solid-angle density, shadow ray up to sqrt(d^2 - eps).
+__device__ inline void sample_area_light(const DevScene& S, int idx, V3 pos, float ux, float uy, V3& radiance, V3& sdir,
+                                         float& stmax, float& lightPdf, V3& normal) {
+  LightRec l;
+  load_light(S, idx, l);
+  float su1 = sqrtf(ux);
+  V2 uv = V2{1.f - su1, uy * su1};
+  V3 p = uv.x * l.v0 + uv.y * l.v1 + (1 - uv.x - uv.y) * l.v2;
+  normal = normalize(uv.x * l.n0 + uv.y * l.n1 + (1 - uv.x - uv.y) * l.n2);
+  V3 dir = p - pos;
+  float pdf = 1.f / (l.area * fabsf(dot(normal, normalize(dir)))) * dot(dir, dir);
+  if (dot(normal, dir) >= 0.f) pdf = 0.f;
+  lightPdf = pdf;
+  radiance = pdf != 0.f ? l.radiance : v3(0.f, 0.f, 0.f);
+  sdir = normalize(dir);
+  stmax = sqrtf(dot(dir, dir) - S.epsilon);
+}
 __device__ inline void sample_one_light(const DevScene& S, uint32_t& rng, V3 pos, V3& radiance, V3& sdir,
                                         float& stmax, float& lightPdf, float& choicePdf) {
   int idx = pick_light(S, rng_uniform(rng), choicePdf);
@@ -207,19 +225,8 @@ __device__ inline void sample_one_light(const DevScene& S, uint32_t& rng, V3 pos
     return;
   }
   if (idx != S.n_lights) {
-    LightRec l;
-    load_light(S, idx, l);
-    float su1 = sqrtf(ux);
-    V2 uv = V2{1.f - su1, uy * su1};
-    V3 p = uv.x * l.v0 + uv.y * l.v1 + (1 - uv.x - uv.y) * l.v2;
-    V3 normal = normalize(uv.x * l.n0 + uv.y * l.n1 + (1 - uv.x - uv.y) * l.n2);
-    V3 dir = p - pos;
-    float pdf = 1.f / (l.area * fabsf(dot(normal, normalize(dir)))) * dot(dir, dir);
-    if (dot(normal, dir) >= 0.f) pdf = 0.f;
-    lightPdf = pdf;
-    radiance = pdf != 0.f ? l.radiance : v3(0.f, 0.f, 0.f);
-    sdir = normalize(dir);
-    stmax = sqrtf(dot(dir, dir) - S.epsilon);
+    V3 normal;
+    sample_area_light(S, idx, pos, ux, uy, radiance, sdir, stmax, lightPdf, normal);
   } else {
     float pdfW;
     V3 dir = uniform_sphere(ux, uy, pdfW);

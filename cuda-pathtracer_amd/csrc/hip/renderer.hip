@@ -1279,6 +1279,41 @@ int caster_trace_rays_static(caster_renderer* r, uint32_t n, const float* origin
   return CASTER_OK;
 }
 
+int caster_eval_function(caster_renderer* r, int fn, uint32_t n, const float* in, float* out) {
+  static const int in_w[CASTER_N_FN] = {16, 16, 6, 3, 8}, out_w[CASTER_N_FN] = {7, 4, 11, 6, 15};
+  if (!r || !in || !out || fn < 0 || fn >= CASTER_N_FN) return fail(CASTER_ERR_ARG, "caster_eval_function: bad argument");
+  if (!r->parts.empty()) return caster_eval_function(r->parts[0], fn, n, in, out);
+  if (n == 0) return CASTER_OK;
+  HIPCHECK(hipSetDevice(r->device));
+  int rc = sync_lanes(r);
+  if (rc) return rc;
+  float *din = nullptr, *dout = nullptr;
+  HIPCHECK(hipMalloc((void**)&din, (size_t)n * in_w[fn] * sizeof(float)));
+  if (hipMalloc((void**)&dout, (size_t)n * out_w[fn] * sizeof(float)) != hipSuccess) {
+    (void)hipFree(din);
+    return fail(CASTER_ERR_DEVICE, "caster_eval_function: out of device memory");
+  }
+  hipStream_t st = r->lanes[0].stream;
+  hipError_t e = hipMemcpy(din, in, (size_t)n * in_w[fn] * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const dim3 grid((n + 63) / 64 < 4096 ? (n + 63) / 64 : 4096), block(64);
+    switch (fn) {
+      case CASTER_FN_SAMPLE_BSDF: hipLaunchKernelGGL(k_hook_sample_bsdf, grid, block, 0, st, r->S, n, (const float*)din, dout); break;
+      case CASTER_FN_EVAL_BSDF: hipLaunchKernelGGL(k_hook_eval_bsdf, grid, block, 0, st, r->S, n, (const float*)din, dout); break;
+      case CASTER_FN_SAMPLE_LIGHT: hipLaunchKernelGGL(k_hook_sample_light, grid, block, 0, st, r->S, n, (const float*)din, dout); break;
+      case CASTER_FN_CAMERA_RAY: hipLaunchKernelGGL(k_hook_camera_ray, grid, block, 0, st, r->S, n, (const float*)din, dout); break;
+      default: hipLaunchKernelGGL(k_hook_hit_record, grid, block, 0, st, r->S, n, (const float*)din, dout); break;
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * out_w[fn] * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(din);
+  (void)hipFree(dout);
+  if (e != hipSuccess) return fail(CASTER_ERR_DEVICE, std::string("caster_eval_function: ") + hipGetErrorString(e));
+  return CASTER_OK;
+}
+
 int caster_get_stats(caster_renderer* r, caster_stats* out) {
   if (!r || !out) return fail(CASTER_ERR_ARG, "caster_get_stats: null argument");
   if (!r->parts.empty()) {   // summed over the devices

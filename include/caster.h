@@ -171,6 +171,24 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids);
 int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, const float* dirs, const float* tmax,
                       int32_t* prim, float* t);
 
+/* Parity hook (no counterpart in the reference): one of the device functions the shade stage is made of, run on
+   `n` input records of the caller's, one record per GPU thread; `in` and `out` are host arrays of n rows of floats
+   (integers travel as their bit patterns).  Material and emitter indices must be valid for the scene.
+     CASTER_FN_SAMPLE_BSDF   SampleBSDF (pathtracer.cu:500-698), radiance transport
+                             in 16: material | wo.xyz | n.xyz | dpdu.xyz | uv.xy | u.xyz | -    out 7: wi.xyz | fr.xyz | pdf
+     CASTER_FN_EVAL_BSDF     Fr (pathtracer.cu:700-818)
+                             in 16: material | wo.xyz | wi.xyz | n.xyz | dpdu.xyz | uv.xy | -   out 4: fr.xyz | pdf
+     CASTER_FN_SAMPLE_LIGHT  Area::SampleLight (area.h:12-17, Triangle.h:146-155)
+                             in 6: emitter | pos.xyz | u.xy       out 11: radiance.xyz | dir.xyz | tmax | normal.xyz | pdf
+     CASTER_FN_CAMERA_RAY    the camera sample of Path() (pathtracer.cu:881-890, Camera.h:45-85)
+                             in 3: x | y | iteration (integers)   out 6: origin.xyz | dir.xyz
+     CASTER_FN_HIT_RECORD    the Intersection record of a hit (Triangle.h:121-141, sphere.h:69-88, line.h:74-84)
+                             in 8: origin.xyz | dir.xyz | t | primitive
+                             out 15: pos.xyz | n.xyz | uv.xy | dpdu.xyz | material, emitter, medium inside, outside */
+enum { CASTER_FN_SAMPLE_BSDF = 0, CASTER_FN_EVAL_BSDF, CASTER_FN_SAMPLE_LIGHT, CASTER_FN_CAMERA_RAY, CASTER_FN_HIT_RECORD,
+       CASTER_N_FN };
+int caster_eval_function(caster_renderer* r, int fn, uint32_t n, const float* in, float* out);
+
 /* caster_trace_rays for callers that cannot allocate device memory (code under HIP
    graph capture, tight serving loops, harnesses that forbid hipMalloc).  No
    counterpart in the reference.  Every pointer is DEVICE memory on the renderer's
