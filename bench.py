@@ -11,13 +11,17 @@ torch.distributed.run, one rank per GPU) every rank renders its own, disjoint
 iterations of the full frame (weak scaling: per-GPU work fixed) and the films
 are summed onto rank 0 with one RCCL reduce inside the timed region.
 
-Rank 0 prints one JSON line.  `roofline` prices the dominant kernel against
-HBM bandwidth with ALGORITHMIC bytes (32 B per BVH node visited + 36 B per
-triangle tested + 16/32 B per sphere/line, plus the ray/hit records the kernel
-itself moves), the per-ray visit counts being those of the reference's own
-traversal order, counted by the CPU oracle on a sample of the same workload.
-`cpu_baseline` is that oracle (a transcription of the reference integrators;
-the reference itself does not compile) timed on this host's cores.
+Started without a launcher, `--gpus N` starts its own N ranks (torch.distributed.run as a child process,
+before anything here touches a GPU) and passes rank 0's line on.
+
+Rank 0 prints one JSON line.  `roofline` prices the kernel with the largest share of the timed region with
+the bytes it itself requests (GPU-side counters: 112 B per 4-wide node record fetched + 48 B per primitive
+record tested + the ray and hit records moved) at the duration of a launch that has the GPU to itself,
+against the roof that applies (L2 bandwidth for the traversal's record gathers, HBM for the shade stage),
+next to the HBM-side traffic of the committed PMC passes and to what the reference's own traversal order
+would have requested (`work_avoided`; visit counts of the CPU oracle on a sample of the same workload).
+`cpu_baseline` is that oracle (a transcription of the reference integrators; the reference itself does not
+compile) timed on this host's cores.
 """
 import argparse
 import importlib
@@ -32,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the eight XCDs
 # what each synthetic scene of tools/gen_scenes.py stands in for among the benchmark configurations
 STAND_IN = {"car_pt": "bmw-m6 stand-in", "stairs_pt": "staircase2 stand-in", "knot_pt": "teapot-full stand-in",
             "cornell_ao": "Cornell box", "cornell_pt": "Cornell box", "cornell_vpt": "Cornell box with a homogeneous medium",
@@ -76,12 +81,12 @@ def algorithmic_bytes_per_ray(counts, kind):
 
 def pmc_traffic_per_launch(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_pmc.json: per-dispatch averages of FETCH_SIZE and WRITE_SIZE, in KiB).
+    command (profiles/r02_pmc.json: per-dispatch averages of FETCH_SIZE and WRITE_SIZE, in KiB).
     FETCH_SIZE counts half the bytes on gfx950, for 16-byte-per-lane streaming reads and for the
     128-byte record gathers of the traversal alike (tools/calib/fetch_calib.hip measures both
     against known byte counts), so it is doubled; WRITE_SIZE is exact.  None without the file."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
             k = json.load(f)[kernel]
         return (2.0 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0
     except (OSError, KeyError, ValueError):
@@ -159,6 +164,7 @@ def main():
     spp = a.spp_per_step
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
     r = caster.Renderer(scene, dev_index, a.iters_in_flight, a.streams)
+    r_streams = a.streams or 3
     npix = scene.width * scene.height
     rows = (0, scene.height)
     if world > 1 and a.shard == "tile":
@@ -253,12 +259,15 @@ def main():
         if not a.no_cpu:
             import oracle_lib as ol
             o = ol.Oracle(path)
-            threads = a.cpu_threads or min(os.cpu_count() or 1, 16)
+            # the oracle on this host's cores: as many threads as there are (64 at most), and one
+            host_cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            threads = a.cpu_threads or min(host_cpus, 64)
             c = ol.Counts()
-            # bounded sample (some 15 s of CPU work): 32 scanlines out of every 128 of the frame, 4 spp;
-            # the oracle hands out whole scanlines, so a block of 32 keeps 16 threads busy
+            # bounded sample (some 15 s of CPU work): `band` scanlines out of every 128 of the frame, 4 spp;
+            # the oracle hands out whole scanlines, so a band holds one scanline per thread at least
             cpu_spp = 4
-            sample_rows = [(y, min(y + 32, scene.height)) for y in range(0, scene.height, 128)]
+            band = max(32, min(threads, 128))
+            sample_rows = [(y, min(y + band, scene.height)) for y in range(0, scene.height, max(128, band))]
             t0 = time.perf_counter()
             for y0, y1 in sample_rows:
                 o.render(1, cpu_spp, threads, counts=c, rows=(y0, y1))
@@ -270,67 +279,100 @@ def main():
             o.render(1, 1, 1, counts=c1, rows=(y_mid, min(y_mid + 16, scene.height)))
             tc1 = time.perf_counter() - t0
             counts = c.as_dict()
-            cpu_model = ""
+            cpu_model, sockets = "", set()
             try:
                 with open("/proc/cpuinfo") as f:
-                    cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+                    for l in f:
+                        if l.startswith("model name") and not cpu_model:
+                            cpu_model = l.split(":", 1)[1].strip()
+                        if l.startswith("physical id"):
+                            sockets.add(l.split(":", 1)[1].strip())
             except OSError:
                 pass
             out["cpu_baseline"] = {
                 "value": n_cpu / tc / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
-                "sample": "%d samples: %d spp on 32 scanlines out of every 128 of the same %dx%d frame" % (
-                    n_cpu, cpu_spp, scene.width, scene.height),
+                "host_logical_cpus": os.cpu_count(), "cpus_this_process_may_use": host_cpus, "sockets": len(sockets) or None,
+                "sample": "%d samples: %d spp on %d scanlines out of every %d of the same %dx%d frame" % (
+                    n_cpu, cpu_spp, band, max(128, band), scene.width, scene.height),
                 "single_thread_msamples_per_s": c1.samples / tc1 / 1e6,
                 "mrays_per_s": sum(counts["rays"]) / tc / 1e6,
             }
-        # Roofline, by kernel symbol as rocprofv3 reports it: k_trace<false> runs the extension and
-        # the probe rays, k_trace<true> the shadow rays, k_shade_* one path vertex per extension ray.
-        # The dominant kernel is the one with the largest total time in the timed region.  With
-        # several streams a launch shares the GPU with the other streams' kernels while it runs, so
-        # `exclusive` repeats the measurement on one stream (same batch size), after the timed region.
+        # Roofline, by kernel symbol as rocprofv3 reports it: k_trace<false> runs the extension and the probe rays,
+        # k_trace<true> the shadow rays, k_shade_* one path vertex per extension ray that hit something.
+        #   requested bytes  what the kernel itself asks the memory system for, from counters it keeps on the GPU:
+        #                    112 B per 4-wide node record fetched (the top of the tree is served from LDS and not
+        #                    counted) + 48 B per primitive record tested + the ray and hit records it moves;
+        #   duration         of a launch that has the GPU to itself (`exclusive`: the one-stream repeat after the
+        #                    timed region; with three streams a launch's wall time includes the time it shares the
+        #                    CUs with the other streams' kernels -- `overlapped`);
+        #   roof             the traversal gathers 128-byte records, most of them from L2 and the per-CU caches (66 MB
+        #                    of nodes and primitives against 32 MB of L2 and 256 MB of Infinity Cache): L2 bandwidth,
+        #                    34.5 TB/s; the shade stage streams path state and gathers 128-byte shading records from
+        #                    a 176 MB table: HBM, 8 TB/s;
+        #   traffic          HBM-side bytes per launch from the committed PMC passes (fabric reads and writes), and
+        #                    traffic / duration against the HBM peak (`hbm_frac`);
+        #   work_avoided     the bytes the REFERENCE's own traversal order would have requested for the same rays
+        #                    (32 B per binary node visited + 36 B per triangle tested, visit counts of the oracle on a
+        #                    sample of this workload) over the requested bytes: what the 4-wide, nearest-first,
+        #                    entry-distance-culled walk saves.
         shade_name = {0: "k_shade_ao", 1: "k_shade_pt<false>", 2: "k_shade_vpt", 3: "k_shade_lt", 4: "k_bdpt"}[scene.integrator]
         if scene.integrator == 1 and kt["probe"][1] == 0:
             shade_name = "k_shade_pt<true>"   # small batches: the probe rays were among the shadow rays, no probe launches
         symbols = {"k_trace<false>": (("extend", 0), ("probe", 2)), "k_trace<true>": (("shadow", 1),),
                    shade_name: (("shade", None),)}
+        ROOF = {"k_trace<false>": ("l2", L2_PEAK_GBS), "k_trace<true>": ("l2", L2_PEAK_GBS), shade_name: ("hbm", HBM_PEAK_GBS)}
 
-        def algorithmic_bytes(sym, rays_now):
-            """Algorithmic bytes the launches of `sym` had to move for `rays_now` = this rank's ray
-            counts [extension, shadow, probe, transmittance]."""
-            if counts is None:
-                return None
+        def requested_bytes(sym, rays_now, walk_now, samples_now):
+            """Bytes the launches of `sym` asked for, for this renderer's ray counts [extension, shadow, probe,
+            transmittance] and traversal counters."""
             if sym == shade_name:
-                # per vertex: ray + hit read (32 + 16 B), path state read + write (2 x 32 B); per accepted
-                # hit: shading fetch 96 B + indices 20 B + material 72 B; per emitted ray: 32 B written
-                vertices = rays_now[0]
-                hit_frac = counts["hits"][0] / max(counts["rays"][0], 1)
-                emitted = max(rays_now[0] - total_samples_rank, 0) + rays_now[1] + rays_now[2]
-                return vertices * (48.0 + 64.0) + vertices * hit_frac * 188.0 + emitted * 32.0
+                # per queue entry: the hit record is read to see whether a vertex is needed (16 B); per vertex:
+                # ray + hit + slot (52 B), path state read and written (2 x 32 B), the pending terms written and
+                # read back (96 B), the shading record (128 B) and the material (96 B); per emitted ray: written to
+                # the staging region, read back and written to the queue (3 x 36 B)
+                entries = rays_now[0]
+                hit_frac = (counts["hits"][0] / max(counts["rays"][0], 1)) if counts else 0.5
+                vertices = entries * hit_frac
+                emitted = max(rays_now[0] - samples_now, 0) + rays_now[1] + rays_now[2]
+                return entries * 16.0 + vertices * (52.0 + 64.0 + 96.0 + 128.0 + 96.0) + emitted * 108.0
+            if sym == "k_trace<true>":
+                return walk_now["any"]["nodes"] * 112.0 + walk_now["any"]["prims"] * 48.0 + rays_now[1] * (32.0 + 4.0)
+            # extension rays write a 16-byte hit record, probe rays too
+            return (walk_now["closest"]["nodes"] * 112.0 + walk_now["closest"]["prims"] * 48.0
+                    + (rays_now[0] + rays_now[2] + rays_now[3]) * (32.0 + 16.0))
+
+        def reference_walk_bytes(sym, rays_now):
+            if counts is None or sym == shade_name:
+                return None
             record = {"extend": 32 + 16, "shadow": 32 + 4, "probe": 32 + 4 + 16}
             return sum(rays_now[kind] * (algorithmic_bytes_per_ray(counts, kind) + record[c]) for c, kind in symbols[sym])
 
-        def roofline_of(sym, times, rays_now):
+        def roofline_of(sym, times, rays_now, walk_now, samples_now):
             ms = sum(times[c][0] for c, _ in symbols[sym])
             launches = sum(times[c][1] for c, _ in symbols[sym])
-            alg = algorithmic_bytes(sym, rays_now)
-            r = {"kernel": sym, "total_ms": ms, "launches": launches, "avg_launch_ms": ms / max(launches, 1)}
-            if alg is not None and ms > 0:
-                r.update(achieved=alg / (ms * 1e-3) / 1e9, frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         algorithmic_bytes_per_launch=alg / max(launches, 1))
-            else:
-                r.update(achieved=None, frac=None)
+            req = requested_bytes(sym, rays_now, walk_now, samples_now)
+            bound, peak = ROOF[sym]
+            r = {"kernel": sym, "bound": bound, "peak": peak, "unit": "GB/s", "total_ms": ms, "launches": launches,
+                 "avg_launch_ms": ms / max(launches, 1), "requested_bytes_per_launch": req / max(launches, 1)}
+            r["achieved"] = req / (ms * 1e-3) / 1e9 if ms > 0 else None
+            r["frac"] = r["achieved"] / peak if ms > 0 else None
+            ref = reference_walk_bytes(sym, rays_now)
+            r["work_avoided"] = ref / req if ref and req else None
+            r["traffic"] = pmc_traffic_per_launch(sym)
+            if r["traffic"] is not None and ms > 0:
+                # (the PMC passes ran the same command: launches of the same average size)
+                r["traffic_over_requested"] = r["traffic"] / r["requested_bytes_per_launch"]
+                r["hbm_frac"] = r["traffic"] * launches / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             return r
 
-        total_samples_rank = st["samples"]
-        per_kernel = [roofline_of(sym, kt, st["rays"]) for sym in symbols]
-        dom = max(per_kernel, key=lambda r: r["total_ms"])
-        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": pmc_traffic_per_launch(dom["kernel"])}
-        roof.update(dom)
-        if counts is not None:
-            kinds = [kind for _, kind in symbols[dom["kernel"]] if kind is not None] or [0]
-            o_rays = sum(counts["rays"][kind] for kind in kinds)
-            roof.update(nodes_per_ray=sum(counts["nodes"][kind] for kind in kinds) / max(o_rays, 1),
-                        tris_per_ray=sum(counts["tris"][kind] for kind in kinds) / max(o_rays, 1))
+        walk = r.walk_counts()
+        per_kernel = [roofline_of(sym, kt, st["rays"], walk, st["samples"]) for sym in symbols]
+        # every launch of the timed region against the wall time: what the three kernels together asked for per second
+        pipeline_req = sum(k["requested_bytes_per_launch"] * k["launches"] for k in per_kernel)
+        roof = {"overlapped": {"streams": r_streams, "kernels": per_kernel,
+                               "requested_bytes_per_step": pipeline_req / max(a.steps, 1),
+                               "requested_rate_gbs": pipeline_req / dt / 1e9,
+                               "note": "launch durations of the timed region: several streams share the GPU"}}
         # one-stream repeat: each launch has the GPU to itself
         try:
             if a.no_exclusive:
@@ -345,17 +387,29 @@ def main():
             t1 = time.perf_counter()
             r1.render(1 + n1, 2 * n1, False)
             dt1 = time.perf_counter() - t1
-            st1, kt1 = r1.stats(), r1.kernel_times()
+            st1, kt1, walk1 = r1.stats(), r1.kernel_times(), r1.walk_counts()
             r1.close()
-            total_samples_rank = st1["samples"]
-            ex = [roofline_of(sym, kt1, st1["rays"]) for sym in symbols]
-            roof["exclusive"] = {"streams": 1, "msamples_per_s": st1["samples"] / dt1 / 1e6,
-                                 "kernels": [{k: v for k, v in e.items() if k in ("kernel", "avg_launch_ms", "achieved", "frac", "launches")}
-                                             for e in ex]}
+            ex = [roofline_of(sym, kt1, st1["rays"], walk1, st1["samples"]) for sym in symbols]
+            dom_name = max(per_kernel, key=lambda k: k["total_ms"])["kernel"]
+            dom = next(k for k in ex if k["kernel"] == dom_name)
+            # the top level: the kernel with the largest share of the timed region, at the duration of a launch
+            # that has the GPU to itself
+            roof.update({k: v for k, v in dom.items()})
+            roof["exclusive"] = {"streams": 1, "msamples_per_s": st1["samples"] / dt1 / 1e6, "kernels": ex,
+                                 "requested_rate_gbs": sum(k["requested_bytes_per_launch"] * k["launches"] for k in ex) / dt1 / 1e9}
+            roof["duration"] = "one-stream repeat after the timed region (a launch has the GPU to itself)"
         except caster.CasterError as e:
+            dom = max(per_kernel, key=lambda k: k["total_ms"])
+            roof.update({k: v for k, v in dom.items()})
             roof["exclusive"] = {"error": str(e)}
-        roof["kernels"] = [{k: v for k, v in e.items() if k in ("kernel", "total_ms", "avg_launch_ms", "achieved", "frac", "launches")}
-                           for e in per_kernel]
+            roof["duration"] = "timed region (launches of several streams overlap)"
+        if counts is not None:
+            o_rays = sum(counts["rays"][:3])
+            roof["reference_walk"] = {"nodes_per_ray": sum(counts["nodes"][:3]) / max(o_rays, 1),
+                                      "tris_per_ray": sum(counts["tris"][:3]) / max(o_rays, 1)}
+        all_rays = max(st["rays"][0] + st["rays"][1] + st["rays"][2], 1)
+        roof["gpu_walk"] = {"node_fetches_per_ray": (walk["closest"]["nodes"] + walk["any"]["nodes"]) / all_rays,
+                            "prim_tests_per_ray": (walk["closest"]["prims"] + walk["any"]["prims"]) / all_rays}
         out["roofline"] = roof
         print(json.dumps(out))
     r.close()

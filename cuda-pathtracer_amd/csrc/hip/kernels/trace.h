@@ -106,6 +106,9 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 #define CASTER_TRACE_WAVES (CASTER_TWO_RAYS ? 4 : 5)
 #endif
 constexpr int kTraceRays = CASTER_TWO_RAYS ? 2 : 1;   // rays per lane
+#ifndef CASTER_REFILL_ANY
+#define CASTER_REFILL_ANY CASTER_REFILL
+#endif
 #ifdef CASTER_WALK_STATS
 // tuning aid: wavefront-level step counts of k_trace, [ANY][counter]
 __device__ unsigned long long g_walk_stats[2][8];
@@ -155,6 +158,8 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       s_top[i] = S.nodes[(size_t)(i / kTopF4) * kNodeF4 + (i % kTopF4)];
     __syncthreads();
   }
+  // (free slots refilled at; an any-hit ray ends abruptly, so its wavefronts run emptier between refills)
+  constexpr int kRefill = ANY ? CASTER_REFILL_ANY : kRefillIdle;
   Stack st{s_stack[wave_in_block], aux.spill + (wave_id * kWave + lane), aux.spill_stride, 0, 0};
   WalkRay a, b;   // the lane's two rays; a's stack is stack 0, b's stack 1
   walk_ray_idle(a);
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
     if (kTraceRays == 2) retire(b);
     // free slots are refilled once there are enough of them
     uint32_t n_idle = (uint32_t)__popcll(__ballot(a.idx < 0)) + (kTraceRays == 2 ? (uint32_t)__popcll(__ballot(b.idx < 0)) : 0u);
-    if (more && n_idle >= (uint32_t)kRefillIdle) {
+    if (more && n_idle >= (uint32_t)kRefill) {
       refill(a);
       if (kTraceRays == 2) refill(b);
     }
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       const int n_busy = __popcll(__ballot(a.cur != kRefEmpty || a.pend != kRefEmpty)) +
                          (kTraceRays == 2 ? __popcll(__ballot(b.cur != kRefEmpty || b.pend != kRefEmpty)) : 0);
       if (n_busy == 0) break;
-      if (more && kTraceRays * kWave - n_busy >= kRefillIdle) break;
+      if (more && kTraceRays * kWave - n_busy >= kRefill) break;
       CASTER_WS(4, n_busy);
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
         CASTER_WS(0, 1);

@@ -205,6 +205,9 @@ __device__ inline float4 lds_f4(const float4* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 constexpr int kTopF4 = 7;
+#ifndef CASTER_BRANCHY_NODE
+#define CASTER_BRANCHY_NODE 0   // 1: the exchange network and the pushes as branches (what the compiler makes of `if`)
+#endif
 template <bool SORT = true>
 __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float tmax, Stack& st, uint32_t lane,
                                 unsigned long long* overflow, const float4* top = nullptr, int n_top = 0) {
@@ -225,6 +228,7 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
   bool h3 = box_test(v3(lx.w, ly.w, lz.w), v3(hx.w, hy.w, hz.w), o, inv, tmax, S.box_scale, k3) && r3 != kRefEmpty;
   int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
   if (nh == 0) return stack_next(st, lane, tmax);
+#if CASTER_BRANCHY_NODE
   k0 = h0 ? k0 : INFINITY; k1 = h1 ? k1 : INFINITY; k2 = h2 ? k2 : INFINITY; k3 = h3 ? k3 : INFINITY;
 #define CASTER_CSWAP(ka, ra, kb, rb)        \
   if (kb < ka) {                             \
@@ -260,6 +264,45 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
   if (nh > 1) ok &= stack_push(st, lane, r1, k1);
   if (!ok) atomicAdd(overflow, 1ull);
   return r0;
+#else
+  // The children that are hit, farthest first, the misses behind them (their key is -infinity): a
+  // five-exchange network written as selects, so that it costs five compares and twenty moves and
+  // no branch.  (A key that is not a number never changes places, and neither does an empty child
+  // slot, which is always behind the children there are: pairs stay pairs.)  The nearest hit is
+  // then item nh-1 and is returned; items 0 .. nh-2 are the deferred ones in the order they must
+  // lie on the stack, farthest at the bottom.  Any-hit rays go the same way: what they find first
+  // does not matter, near boxes first is as good an order as any.
+  k0 = h0 ? k0 : -INFINITY; k1 = h1 ? k1 : -INFINITY; k2 = h2 ? k2 : -INFINITY; k3 = h3 ? k3 : -INFINITY;
+#define CASTER_CSWAP(ka, ra, kb, rb)                                   \
+  {                                                                     \
+    const bool c_ = ka < kb;                                            \
+    const float nka_ = c_ ? kb : ka, nkb_ = c_ ? ka : kb;               \
+    const int nra_ = c_ ? rb : ra, nrb_ = c_ ? ra : rb;                 \
+    ka = nka_; kb = nkb_; ra = nra_; rb = nrb_;                         \
+  }
+  CASTER_CSWAP(k0, r0, k1, r1)
+  CASTER_CSWAP(k2, r2, k3, r3)
+  CASTER_CSWAP(k0, r0, k2, r2)
+  CASTER_CSWAP(k1, r1, k3, r3)
+  CASTER_CSWAP(k1, r1, k2, r2)
+#undef CASTER_CSWAP
+  const int nearest = nh > 3 ? r3 : (nh > 2 ? r2 : (nh > 1 ? r1 : r0));
+  if (st.sp + 3 <= kLdsDepth) {
+    // three stores at fixed distances from one address; those beyond the new top of the stack (a
+    // miss, or the nearest hit itself) are never read
+    lds_put(st, st.sp, lane, make_uint2((uint32_t)r0, __float_as_uint(k0)));
+    lds_put(st, st.sp + 1, lane, make_uint2((uint32_t)r1, __float_as_uint(k1)));
+    lds_put(st, st.sp + 2, lane, make_uint2((uint32_t)r2, __float_as_uint(k2)));
+    st.sp += nh - 1;
+  } else {
+    bool ok = true;
+    if (nh > 1) ok &= stack_push(st, lane, r0, k0);
+    if (nh > 2) ok &= stack_push(st, lane, r1, k1);
+    if (nh > 3) ok &= stack_push(st, lane, r2, k2);
+    if (!ok) atomicAdd(overflow, 1ull);
+  }
+  return nearest;
+#endif
 }
 
 // Tests the primitives of the leaf starting at `i`.  Among hits at equal

@@ -383,7 +383,7 @@ static int dev_upload(caster_renderer* r, const T** out, const std::vector<T>& v
 }
 
 #ifndef CASTER_PROBE_ANY_MAX_SLOTS
-#define CASTER_PROBE_ANY_MAX_SLOTS (40u << 20)  // path slots in flight up to which probe rays ride the shadow queue (1080p: 19 iterations)
+#define CASTER_PROBE_ANY_MAX_SLOTS 0xffffffffu  // path slots in flight up to which probe rays ride the shadow queue (every batch size)
 #endif
 static int alloc_queue(caster_renderer* r, RayQueue& q, uint32_t n, bool with_hit, uint32_t* counter) {
   int rc;
@@ -548,9 +548,12 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     // Every probe ray of the path tracer then starts out with the nearest emitter on its line, and can be
     // settled in k_shade_pt<true> but for its visibility (see there): two launches less per bounce, for a
     // heavier shade kernel.  Against a closest-hit probe queue with a resolve kernel of its own, 1080p on
-    // 1.37 M triangles: +19 % with one iteration in flight (678 -> 804 Msamples/s), +7 % with four, +3 %
-    // with sixteen, 1.5 % slower with sixty-four: small batches take it, large ones keep the probe queue.
-    r->probe_any = CASTER_PROBE_CULL && sc.integrator == IT_PT && !sc.infinite.valid &&
+    // 1.37 M triangles: +19 % with one iteration in flight, +7 % with four, +3 % with sixteen, and with
+    // sixty-four +1 ... +3 % (1757 against 1696-1742 Msamples/s; 1.5 % slower before the shade stage
+    // shaded hits only): every batch size takes it.
+    // (CASTER_PROBE_QUEUE=1 in the environment keeps the probe queue: a knob for tests and measurements)
+    const char* keep_queue = getenv("CASTER_PROBE_QUEUE");
+    r->probe_any = !(keep_queue && keep_queue[0] == '1') && CASTER_PROBE_CULL && sc.integrator == IT_PT && !sc.infinite.valid &&
                    (int)sc.lights.size() <= kProbeCullLights && (uint64_t)r->pool_slots <= (uint64_t)CASTER_PROBE_ANY_MAX_SLOTS;
     // light tracing sends its connection rays through the traversal kernel unless a medium is a
     // density grid (its transmittance draws random numbers) -- or the scene is a handful of

@@ -111,15 +111,19 @@ def test_splatting_integrators_at_full_size(caster, tmp_path, integrator):
     assert whole.mean() > 1e-4 and float(np.sqrt(np.mean(d * d))) <= 1e-5
 
 
-def test_probe_rays_as_occlusion_rays_or_on_their_own_queue(caster, tmp_path):
+def test_probe_rays_as_occlusion_rays_or_on_their_own_queue(caster, tmp_path, monkeypatch):
     """Without an environment and with few emitters the BSDF-sampled probe of a path-tracing vertex
-    knows its emitter: small batches send it among the shadow rays as an occlusion ray, large ones
-    keep the closest-hit probe queue.  Same film bit for bit, same ray statistics."""
+    knows its emitter and goes among the shadow rays as an occlusion ray; otherwise (or with
+    CASTER_PROBE_QUEUE=1) the probes keep a closest-hit queue of their own.  Same film bit for bit,
+    same ray statistics, at a small and a large batch size."""
     path = gen_scenes.generate(str(tmp_path / "stairs"), "stairs_pt", 0.3, 1920, 1080, 8)
     sc = caster.Scene(path)
     out = {}
     for k in (2, 24):   # 24 iterations of 1080p in flight: 50 M path slots
+        if k == 24:
+            monkeypatch.setenv("CASTER_PROBE_QUEUE", "1")
         r = caster.Renderer(sc, 0, k)
+        monkeypatch.delenv("CASTER_PROBE_QUEUE", raising=False)
         r.render(1, 24, True)
         out[k] = (r.read_film(2), r.stats())
         r.close()

@@ -10,10 +10,10 @@ d = json.loads([l for l in open('gpurun_out/p.json') if l.startswith('{')][-1])
 print('%-28s %8.1f Msamples/s' % (sys.argv[1], d['value']), {k: round(v) for k, v in d['kernel_ms'].items()})
 PY
 done <<'LIST'
-3 32 96
-3 48 144
-3 64 192
-4 32 128
-4 48 192
-6 32 192
+1 192 192
+1 256 256
+2 160 320
+2 176 352
+3 96 288
+3 104 312
 LIST
