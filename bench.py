@@ -354,12 +354,12 @@ def main():
             bound, peak = ROOF[sym]
             r = {"kernel": sym, "bound": bound, "peak": peak, "unit": "GB/s", "total_ms": ms, "launches": launches,
                  "avg_launch_ms": ms / max(launches, 1), "requested_bytes_per_launch": req / max(launches, 1)}
-            r["achieved"] = req / (ms * 1e-3) / 1e9 if ms > 0 else None
-            r["frac"] = r["achieved"] / peak if ms > 0 else None
+            r["achieved"] = req / (ms * 1e-3) / 1e9 if ms > 0 and req > 0 else None
+            r["frac"] = r["achieved"] / peak if r["achieved"] is not None else None
             ref = reference_walk_bytes(sym, rays_now)
             r["work_avoided"] = ref / req if ref and req else None
             r["traffic"] = pmc_traffic_per_launch(sym)
-            if r["traffic"] is not None and ms > 0:
+            if r["traffic"] is not None and ms > 0 and req > 0:
                 # (the PMC passes ran the same command: launches of the same average size)
                 r["traffic_over_requested"] = r["traffic"] / r["requested_bytes_per_launch"]
                 r["hbm_frac"] = r["traffic"] * launches / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS

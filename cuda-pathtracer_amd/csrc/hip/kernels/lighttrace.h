@@ -224,11 +224,9 @@ __global__ __launch_bounds__(kWave) void k_shade_lt(LaunchCtx L, RayQueue cur, S
   const PathState& P = L.P;
   const uint32_t count = *cur.count;
   uint32_t stat_tr = 0;
-  uint32_t r0, r1;
-  wave_rounds(count, r0, r1);
   const uint32_t sbase = blockIdx.x * stage.region_cap;
   uint32_t n_next = 0, n_conn = 0, n_list = 0;
-  for (uint32_t r = r0; r < r1; ++r) {
+  CASTER_FOR_ROUNDS_LT(r, count) {
     uint32_t idx = r * kWave + threadIdx.x;
     bool want_next = false, want_conn = false;
     int slot = 0;

@@ -48,14 +48,35 @@ __device__ inline void stage_flush(const RayQueue& stage, uint32_t base, uint32_
     fin.slot[off + i] = stage.slot[base + i];
   }
 }
-// The rounds (groups of 64 queue entries) wavefront `blockIdx.x` shades: a
-// contiguous range, so that the compacted output keeps the input's order.
-__device__ inline void wave_rounds(uint32_t count, uint32_t& r0, uint32_t& r1) {
-  uint32_t rounds = (count + kWave - 1) / kWave;
-  uint32_t per = (rounds + gridDim.x - 1) / gridDim.x;
-  r0 = blockIdx.x * per;
-  r1 = r0 + per < rounds ? r0 + per : rounds;
-}
+// The rounds (groups of 64 queue entries) wavefront `blockIdx.x` shades: chunks of CASTER_SHADE_CHUNK
+// consecutive rounds dealt to the wavefronts round-robin, so that each sees a sample of the whole image.
+// (A contiguous range per wavefront made the cost per wavefront follow the image -- sky here, car paint
+// there -- and a launch as long as its dearest range: the path tracer's shade launches were 15 % longer.)
+#ifndef CASTER_SHADE_CHUNK
+#define CASTER_SHADE_CHUNK 8
+#endif
+// (the kernels that walk the tree in place, lane by lane, keep a contiguous range per wavefront: their cost is the
+// walks, and neighbouring rounds walk the same part of the tree -- the volumetric integrator with a density grid ran
+// 21 % slower with its rounds dealt round-robin)
+#define CASTER_FOR_ROUNDS_CONTIGUOUS(r, count)                                                               \
+  for (uint32_t all_ = ((count) + kWave - 1) / kWave, per_ = (all_ + gridDim.x - 1) / gridDim.x,             \
+                r = blockIdx.x * per_, end_ = r + per_ < all_ ? r + per_ : all_;                             \
+       r < end_; ++r)
+// (measured with their rounds dealt round-robin instead: AO on the Cornell box 5979 against 6109 Msamples/s, the
+// queued volumetric integrator 412 against 447, light tracing on the benchmark scene 1256 against 1313)
+#ifndef CASTER_FOR_ROUNDS_AO
+#define CASTER_FOR_ROUNDS_AO CASTER_FOR_ROUNDS_CONTIGUOUS
+#endif
+#ifndef CASTER_FOR_ROUNDS_LT
+#define CASTER_FOR_ROUNDS_LT CASTER_FOR_ROUNDS_CONTIGUOUS
+#endif
+#ifndef CASTER_FOR_ROUNDS_VPTQ
+#define CASTER_FOR_ROUNDS_VPTQ CASTER_FOR_ROUNDS_CONTIGUOUS
+#endif
+#define CASTER_FOR_ROUNDS(r, count)                                                                          \
+  for (uint32_t c0_ = blockIdx.x * CASTER_SHADE_CHUNK, all_ = ((count) + kWave - 1) / kWave; c0_ < all_;       \
+       c0_ += gridDim.x * CASTER_SHADE_CHUNK)                                                                 \
+    for (uint32_t r = c0_; r < c0_ + CASTER_SHADE_CHUNK && r < all_; ++r)
 
 // Adds the two direct-light terms left pending by the previous vertex:
 // Li += beta * (Ld_light + Ld_bsdf)  (pathtracer.cu:984).
@@ -98,9 +119,6 @@ __device__ inline V3 probe_emitter_term(const DevScene& S, int prim, V3 pos, V3 
 // extension ray has been traced.
 #ifndef CASTER_SHADE_WAVES
 #define CASTER_SHADE_WAVES 4
-#endif
-#ifndef CASTER_SHADE_CHUNK
-#define CASTER_SHADE_CHUNK 8   // rounds (of 64 queue entries) per chunk; chunks are dealt to the shade wavefronts round-robin
 #endif
 #ifndef CASTER_SHADE_SORT
 #define CASTER_SHADE_SORT 0    // 1: vertices are shaded in groups of one material type; 0: in groups of hits of any type
@@ -326,15 +344,14 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
   // ring buffers: lane c keeps the start and the length of list c
   uint32_t q_head = 0, q_len = 0;
   const bool env = S.inf.valid != 0;
-  const uint32_t rounds_all = (count + kWave - 1) / kWave;
   auto take_group = [&](int c, uint32_t n) {   // the first n (<= 64) entries of list c, one per lane
     uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)q_head, c);
     uint32_t my = s_list[c][(head + lane) & (kShadeListCap - 1)];
     if ((int)lane == c) { q_head = (q_head + n) & (kShadeListCap - 1); q_len -= n; }
     return my;
   };
-  for (uint32_t c0 = blockIdx.x * CASTER_SHADE_CHUNK; c0 < rounds_all; c0 += gridDim.x * CASTER_SHADE_CHUNK) {
-    for (uint32_t r = c0; r < c0 + CASTER_SHADE_CHUNK && r < rounds_all; ++r) {
+  {
+    CASTER_FOR_ROUNDS(r, count) {
       const uint32_t idx = r * kWave + lane;
       int cls = -1;
       if (idx < count) {
@@ -429,11 +446,9 @@ __global__ __launch_bounds__(kWave) void k_shade_ao(LaunchCtx L, RayQueue cur, S
   const DevScene& S = L.S;
   const PathState& P = L.P;
   const uint32_t count = *cur.count;
-  uint32_t r0, r1;
-  wave_rounds(count, r0, r1);
   const uint32_t sbase = blockIdx.x * stage.region_cap;
   uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
-  for (uint32_t r = r0; r < r1; ++r) {
+  CASTER_FOR_ROUNDS_AO(r, count) {
     uint32_t idx = r * kWave + threadIdx.x;
     bool want_shadow = false;
     int slot = 0;

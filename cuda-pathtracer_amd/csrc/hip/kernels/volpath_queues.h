@@ -44,11 +44,9 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_vptq(Launch
   const DevScene& S = L.S;
   const PathState& P = L.P;
   const uint32_t count = *cur.count;
-  uint32_t r0, r1;
-  wave_rounds(count, r0, r1);
   const uint32_t sbase = blockIdx.x * stage.region_cap;
   uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
-  for (uint32_t r = r0; r < r1; ++r) {
+  CASTER_FOR_ROUNDS_VPTQ(r, count) {
     uint32_t idx = r * kWave + threadIdx.x;
     bool want_next = false, want_shadow = false, want_probe = false;
     int slot = 0;
@@ -266,11 +264,9 @@ __global__ __launch_bounds__(kWave) void k_tr_step(LaunchCtx L, RayQueue cur, Ra
   const DevScene& S = L.S;
   const PathState& P = L.P;
   const uint32_t count = *cur.count;
-  uint32_t r0, r1;
-  wave_rounds(count, r0, r1);
   const uint32_t sbase = blockIdx.x * stage.region_cap;
   uint32_t n_next = 0;
-  for (uint32_t r = r0; r < r1; ++r) {
+  CASTER_FOR_ROUNDS_VPTQ(r, count) {
     uint32_t idx = r * kWave + threadIdx.x;
     bool want = false;
     int slot = 0;
