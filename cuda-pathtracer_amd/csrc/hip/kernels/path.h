@@ -121,7 +121,7 @@ __device__ inline V3 probe_emitter_term(const DevScene& S, int prim, V3 pos, V3 
 #define CASTER_SHADE_WAVES 4
 #endif
 #ifndef CASTER_SHADE_SORT
-#define CASTER_SHADE_SORT 0    // 1: vertices are shaded in groups of one material type; 0: in groups of hits of any type
+#define CASTER_SHADE_SORT 1    // 1: vertices are shaded in groups of one material type; 0: in groups of hits of any type
 #endif
 #ifndef CASTER_PROBE_CULL
 #define CASTER_PROBE_CULL 1
@@ -321,17 +321,15 @@ __device__ inline void shade_pt_vertices(const LaunchCtx& L, const RayQueue& cur
 // Which queue entries need a vertex: a ray that hit nothing ends its path, and unless the scene has
 // an environment light nothing is left to do for it (what the path still owes from its previous
 // vertex is added by k_finish); in an open scene that is half the queue, and a vertex is some
-// 3000 vector instructions that those lanes would sit through.  So a wavefront first collects the
-// entries of a round that need a vertex in a short list in LDS and shades the list whenever it
-// holds 64: every lane of a group then has a vertex.  What is left in the list when the
-// wavefront's work is over is shaded as a partial group.  With CASTER_SHADE_SORT there is a list
-// per material type (and one for the misses an environment light makes count), so that all 64
-// lanes of a group run the same material's code; measured on the benchmark scene that is no gain
-// over the single list (neighbouring paths mostly meet the same material anyway, and rare
-// materials wait in their list until their rays are far apart): 1705-1720 against 1744 Msamples/s.
-// The wavefronts take chunks of CASTER_SHADE_CHUNK rounds round-robin, so that each sees a sample
-// of the whole image (a contiguous range per wavefront made the cost per wavefront follow the
-// image -- sky here, car paint there -- and the launch as long as its dearest range: -15 %).
+// 3000 vector instructions that those lanes would sit through.  And what a vertex costs is mostly
+// arithmetic of ITS material.  So a wavefront first sorts the entries of a round that need a
+// vertex into short lists in LDS, one per material type (and one for the misses an environment
+// light makes count), and shades a list whenever it holds 64: every lane of a group then has a
+// vertex, and all 64 run the same material's code.  What is left in the lists when the
+// wavefront's work is over is shaded as partial groups.  Measured (Msamples/s, one list for all
+// hits against a list per material): staircase 897 / 912, torus knot 1448 / 1468, benchmark scene
+// 1733 / 1734 -- most of the gain is in leaving out the misses, neighbouring paths mostly meet
+// the same material anyway.
 constexpr int kShadeLists = CASTER_SHADE_SORT ? 7 : 1;  // material types 0..5, misses under an environment light
 constexpr int kShadeListCap = 128;                      // a list is emptied as soon as it reaches 64: 63 + 64 at most
 template <bool PROBE_ANY>

@@ -11,9 +11,8 @@ d = json.loads([l for l in open('gpurun_out/c.json') if l.startswith('{')][-1])
 print('%-40s %-60s %8.1f Msamples/s' % (sys.argv[1][-40:], d['config']['workload'][:60] + ' ' + sys.argv[2], d['value']), {k: round(v) for k, v in d['kernel_ms'].items()})
 PY
 done <<'LIST'
-cornell_ao 512 512 0
-cornell_vpt 1024 1024 16
-car_pt 1920 1080 8 lt
-cornell_pt 1024 1024 8 lt
+stairs_pt 1920 1080 8
+knot_pt 1024 1024 8
+car_pt 1920 1080 8
 LIST
 done
