@@ -120,7 +120,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--integrator", default=None, help="render the scene with this integrator instead of its own (experiments)")
-    ap.add_argument("--spp-per-step", type=int, default=192)
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="samples per pixel per step (0: one batch on every stream, i.e. streams x iterations in flight)")
     ap.add_argument("--iters-in-flight", type=int, default=0, help="iterations per batch of paths (0: library default)")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams batches are dealt to (0: library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline (roofline then uses no counts)")
@@ -161,10 +162,10 @@ def main():
     caster = importlib.import_module("cuda-pathtracer_amd")
     path = scene_path(a.scene, a.detail, a.width, a.height, a.depth, rank, barrier, a.integrator)
     scene = caster.Scene(path)
-    spp = a.spp_per_step
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
     r = caster.Renderer(scene, dev_index, a.iters_in_flight, a.streams)
     r_streams = a.streams or 3
+    spp = a.spp_per_step or r_streams * r.iters_in_flight
     npix = scene.width * scene.height
     rows = (0, scene.height)
     if world > 1 and a.shard == "tile":
@@ -366,6 +367,8 @@ def main():
             return r
 
         walk = r.walk_counts()
+        iters_in_flight = r.iters_in_flight
+        r.close()    # (its path pools take most of the card: the one-stream repeat below needs a third as much again)
         per_kernel = [roofline_of(sym, kt, st["rays"], walk, st["samples"]) for sym in symbols]
         # every launch of the timed region against the wall time: what the three kernels together asked for per second
         pipeline_req = sum(k["requested_bytes_per_launch"] * k["launches"] for k in per_kernel)
@@ -377,10 +380,10 @@ def main():
         try:
             if a.no_exclusive:
                 raise caster.CasterError(0, "skipped (--no-exclusive)")
-            r1 = caster.Renderer(scene, dev_index, r.iters_in_flight, 1)
+            r1 = caster.Renderer(scene, dev_index, iters_in_flight, 1)
             if rows != (0, scene.height):
                 r1.set_row_stripes(*rows)
-            n1 = r.iters_in_flight
+            n1 = iters_in_flight
             r1.render(1, n1, True)
             r1.reset_stats()
             r1.set_profiling(True)

@@ -265,6 +265,37 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
   if (!ok) atomicAdd(overflow, 1ull);
   return r0;
 #else
+  if (!SORT) {
+    // An occlusion ray: its tmax never shrinks, so the order in which boxes are visited decides nothing and a
+    // deferred box that passed the test once would pass it again -- the children that are hit are moved to the
+    // front by a five-exchange network on the hit flags (selects, no branch), no entry distances are kept.
+#define CASTER_CMOVE(ha, ra, hb, rb)                     \
+    {                                                     \
+      const bool c_ = !ha && hb;                          \
+      const int nra_ = c_ ? rb : ra, nrb_ = c_ ? ra : rb; \
+      const bool nha_ = ha || hb, nhb_ = ha && hb;        \
+      ra = nra_; rb = nrb_; ha = nha_; hb = nhb_;         \
+    }
+    CASTER_CMOVE(h0, r0, h1, r1)
+    CASTER_CMOVE(h2, r2, h3, r3)
+    CASTER_CMOVE(h0, r0, h2, r2)
+    CASTER_CMOVE(h1, r1, h3, r3)
+    CASTER_CMOVE(h1, r1, h2, r2)
+#undef CASTER_CMOVE
+    if (st.sp + 3 <= kLdsDepth) {
+      lds_put(st, st.sp, lane, make_uint2((uint32_t)r1, 0u));
+      lds_put(st, st.sp + 1, lane, make_uint2((uint32_t)r2, 0u));
+      lds_put(st, st.sp + 2, lane, make_uint2((uint32_t)r3, 0u));
+      st.sp += nh - 1;
+    } else {
+      bool ok = true;
+      if (nh > 1) ok &= stack_push(st, lane, r1, 0.f);
+      if (nh > 2) ok &= stack_push(st, lane, r2, 0.f);
+      if (nh > 3) ok &= stack_push(st, lane, r3, 0.f);
+      if (!ok) atomicAdd(overflow, 1ull);
+    }
+    return r0;
+  }
   // The children that are hit, farthest first, the misses behind them (their key is -infinity): a
   // five-exchange network written as selects, so that it costs five compares and twenty moves and
   // no branch.  (A key that is not a number never changes places, and neither does an empty child

@@ -517,7 +517,8 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   if (default_pool) {
     // late bounces keep few rays alive: a batch needs tens of millions of paths
     // for their launches to fill the chip (the pools are sized for 288 GB of HBM:
-    // 128 M slots x 380 B per stream)
+    // 128 M slots x 380 B per stream; 192 M slots -- 96 iterations of 1080p -- measured no faster: 1753
+    // against 1757 Msamples/s)
     long long target = 128ll << 20;
     iters_in_flight = (int)std::max<long long>(1, std::min<long long>(64, target / S.slots_per_iter));
   }
@@ -948,6 +949,19 @@ int caster_begin_streams(const caster_scene* s, int device_id, int iters_in_flig
       return fail(CASTER_ERR_SCENE, "caster_begin: a shape without a material needs the vpt integrator");
   caster_renderer* r = new caster_renderer();
   int rc = begin_impl(s->scene, device_id, iters_in_flight, n_streams, r);
+  // Default pools are sized from the memory that is free at that moment; when another renderer took its share
+  // in the meantime (several processes on one GPU), the allocation fails and the pools are halved until they fit.
+  while (rc == CASTER_ERR_DEVICE && iters_in_flight <= 0 && r->iters_in_flight > 1) {
+    const int smaller = r->iters_in_flight / 2;
+    const int streams = (int)r->lanes.size();
+    std::string keep = g_last_error;
+    caster_end(r);
+    (void)hipGetLastError();   // (the failed allocation is not to be found by the next launch check)
+    r = new caster_renderer();
+    rc = begin_impl(s->scene, device_id, smaller, streams, r);
+    if (rc == CASTER_ERR_DEVICE && smaller == 1) { g_last_error = keep; break; }
+    if (rc == CASTER_ERR_DEVICE) r->iters_in_flight = smaller;   // (so that the next round halves again)
+  }
   if (rc) { caster_end(r); return rc; }
   *out = r;
   return CASTER_OK;

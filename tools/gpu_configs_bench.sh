@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 : > gpurun_out/configs.txt
 while read name w h depth; do
-timeout -k 10 300 python -u bench.py --steps 3 --warmup 1 --no-cpu --no-exclusive --spp-per-step 192 --scene $name --width $w --height $h --depth $depth > gpurun_out/c.json 2> gpurun_out/c.err || { echo "$name FAILED"; tail -3 gpurun_out/c.err; continue; }
+timeout -k 10 300 python -u bench.py --steps 3 --warmup 1 --no-cpu --no-exclusive --scene $name --width $w --height $h --depth $depth > gpurun_out/c.json 2> gpurun_out/c.err || { echo "$name FAILED"; tail -3 gpurun_out/c.err; continue; }
 python - <<'PY' | tee -a gpurun_out/configs.txt
 import json
 d = json.loads([l for l in open('gpurun_out/c.json') if l.startswith('{')][-1])

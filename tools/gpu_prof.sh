@@ -8,7 +8,7 @@ ARGS="bench.py --steps 2 --warmup 1 --no-cpu --no-exclusive"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace -o t --output-format csv -- python3 $ARGS > gpurun_out/prof/trace.log 2>&1
 echo trace done
 # the same on one stream: every launch has the GPU to itself (the durations bench.py's `exclusive` block reports)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace1 -o t --output-format csv -- python3 $ARGS --streams 1 --spp-per-step 64 > gpurun_out/prof/trace1.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace1 -o t --output-format csv -- python3 $ARGS --streams 1 > gpurun_out/prof/trace1.log 2>&1
 echo trace1 done
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d gpurun_out/prof/pmc1 -o p --output-format csv -- python3 $ARGS > gpurun_out/prof/pmc1.log 2>&1
 echo pmc1 done

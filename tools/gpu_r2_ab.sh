@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 for lib in cuda-pathtracer_amd/libcaster.so cuda-pathtracer_amd/variants/contig.so; do
 while read name w h depth integ; do
 extra=""; [ -n "$integ" ] && extra="--integrator $integ"
-CASTER_LIB=$PWD/$lib timeout -k 10 300 python -u bench.py --steps 3 --warmup 1 --no-cpu --no-exclusive --spp-per-step 192 --scene $name --width $w --height $h --depth $depth $extra > gpurun_out/c.json 2> gpurun_out/c.err || { echo "$name FAILED"; tail -3 gpurun_out/c.err; continue; }
+CASTER_LIB=$PWD/$lib timeout -k 10 300 python -u bench.py --steps 3 --warmup 1 --no-cpu --no-exclusive --scene $name --width $w --height $h --depth $depth $extra > gpurun_out/c.json 2> gpurun_out/c.err || { echo "$name FAILED"; tail -3 gpurun_out/c.err; continue; }
 python - "$lib" "$integ" <<'PY'
 import json, sys
 d = json.loads([l for l in open('gpurun_out/c.json') if l.startswith('{')][-1])

@@ -3,7 +3,7 @@ set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 rm -rf gpurun_out/lt1; mkdir -p gpurun_out/lt1
-timeout -k 10 300 rocprofv3 --kernel-trace -d gpurun_out/lt1 -o t --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-exclusive --streams 1 --spp-per-step 64 > gpurun_out/lt1/log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace -d gpurun_out/lt1 -o t --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-exclusive --streams 1 > gpurun_out/lt1/log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/lt1/**/*kernel_trace.csv', recursive=True)[0]
