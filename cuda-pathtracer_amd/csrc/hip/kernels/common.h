@@ -65,6 +65,9 @@ __device__ inline float length(V3 v) { return sqrtf(dot(v, v)); }
 __device__ inline V3 normalize(V3 v) { return v * fps::rsqrt_(dot(v, v)); }
 __device__ inline V3 vabs(V3 v) { return V3{fabsf(v.x), fabsf(v.y), fabsf(v.z)}; }
 __device__ inline float maxcomp(V3 a) { return fps::fmax_(fps::fmax_(a.x, a.y), a.z); }
+// maxcomp(vabs(a)) as one v_max3_f32 with |.| operands: among non-negative numbers the native maximum picks the value
+// fps::fmax_ picks (it drops a NaN operand as fmax_ does, and no zero here carries a sign).
+__device__ inline float maxabs3(V3 a) { return __builtin_fmaxf(__builtin_fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)); }
 __device__ inline bool is_black(V3 c) { return c.x == 0 && c.y == 0 && c.z == 0; }
 __device__ inline bool isinf_(float v) { return v == INFINITY || v == -INFINITY; }
 __device__ inline bool has_nan(V3 c) { return c.x != c.x || c.y != c.y || c.z != c.z; }

@@ -75,7 +75,7 @@ __global__ void k_hook_hit_record(DevScene S, uint32_t n, const float* in, float
     h.t = r[6]; h.prim = __float_as_int(r[7]); h.b1 = h.b2 = 0.f;
     float t, b1, b2;
     bool last;
-    if (prim_test(S, h.prim, o, d, maxcomp(vabs(d)), S.epsilon, INFINITY, t, b1, b2, last)) { h.b1 = b1; h.b2 = b2; }
+    if (prim_test(S, h.prim, o, d, maxabs3(d), S.epsilon, INFINITY, t, b1, b2, last)) { h.b1 = b1; h.b2 = b2; }
     Isect is;
     load_isect(S, o, d, h, is);
     float* q = out + 15 * (size_t)i;

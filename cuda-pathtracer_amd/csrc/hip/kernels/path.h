@@ -239,7 +239,7 @@ __device__ inline void shade_pt_vertices(const LaunchCtx& L, const RayQueue& cur
                 want_probe = false;
                 py = make_float4(0, 0, 0, 0);
               } else if (S.n_lights <= kProbeCullLights) {
-                float pmaxD = maxcomp(vabs(mo));
+                float pmaxD = maxabs3(mo);
                 float pb1 = 0.f, pb2 = 0.f;
                 for (int li = 0; li < S.n_lights; ++li) {
                   int lprim = __float_as_int(uniform_load4(S.lights + (size_t)li * kLightF4 + 4).w);
@@ -414,7 +414,7 @@ __device__ inline void probe_resolve_one(const LaunchCtx& L, V3 pos, V3 out, Hit
     // a hit the ray started out with carries no barycentrics: the same test gives them again
     float t, b1, b2;
     bool last;
-    if (prim_test(S, h.prim, pos, out, maxcomp(vabs(out)), S.epsilon, INFINITY, t, b1, b2, last)) {
+    if (prim_test(S, h.prim, pos, out, maxabs3(out), S.epsilon, INFINITY, t, b1, b2, last)) {
       h.b1 = b1; h.b2 = b2;
     }
     y = probe_emitter_term(S, h.prim, pos, out, h.t, h.b1, h.b2, fr, pdf, absdot);

@@ -111,7 +111,7 @@ constexpr int kTraceRays = CASTER_TWO_RAYS ? 2 : 1;   // rays per lane
 #endif
 #ifdef CASTER_WALK_STATS
 // tuning aid: wavefront-level step counts of k_trace, [ANY][counter]
-__device__ unsigned long long g_walk_stats[2][8];
+__device__ unsigned long long g_walk_stats[2][16];
 #define CASTER_WS(i, v) ws[i] += (unsigned long long)(v)
 #else
 #define CASTER_WS(i, v)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       float4 o4 = q.o[r.idx], d4 = q.d[r.idx];
       r.o = v3(o4); r.d = v3(d4);
       r.inv = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
-      r.maxD = maxcomp(vabs(r.d));
+      r.maxD = maxabs3(r.d);
       // every queued ray starts at the scene's epsilon; o.w carries a hit known
       // beforehand (a probe ray's nearest emitter, at distance tmax) or -1
       r.hit.t = d4.w; r.hit.prim = __float_as_int(o4.w); r.hit.b1 = r.hit.b2 = 0.f;
@@ -298,6 +298,8 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
         CASTER_WS(0, 1);
         CASTER_WS(1, n_inner);
+        CASTER_WS(5, __any(a.cur >= 0 && a.sp + 3 > kLdsDepth) ? 1 : 0);
+        CASTER_WS(7, __popcll(__ballot(a.cur >= 0)) * 0 + __popcll(__ballot(a.cur >= 0 && a.sp + 3 > kLdsDepth)));
         // the lane's first ray if it stands at a node, else its second
         const bool w = kTraceRays == 2 && !node_a;
         int cur = pick(w, a.cur, b.cur);
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
           cur = node_step<!ANY || !CASTER_ANY_UNSORTED>(S, cur, o, inv, tmax, st, lane, overflow, s_top, n_top);
           if (cur < 0 && cur != kRefEmpty && pend == kRefEmpty) {
             pend = cur;
-            cur = stack_next(st, lane, tmax);
+            cur = stack_next_of<!ANY || !CASTER_ANY_UNSORTED>(st, lane, tmax);
           }
           put(w, a.cur, b.cur, cur);
           put(w, a.pend, b.pend, pend);
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
             st.sp = pick(w, a.sp, b.sp);
             st.ctx = w ? 1 : 0;
             pend = cur;
-            cur = stack_next(st, lane, ht);
+            cur = stack_next_of<!ANY || !CASTER_ANY_UNSORTED>(st, lane, ht);
             put(w, a.sp, b.sp, st.sp);
           }
           put(w, a.cur, b.cur, cur);
@@ -375,6 +377,11 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
 #ifdef CASTER_WALK_STATS
   if (lane == 0)
     for (int k = 0; k < 8; ++k) atomicAdd(&g_walk_stats[ANY ? 1 : 0][k], ws[k]);
+  atomicAdd(&g_walk_stats[ANY ? 1 : 0][8], (unsigned long long)st.n_pop_calls);
+  atomicAdd(&g_walk_stats[ANY ? 1 : 0][9], (unsigned long long)st.n_pop_iters);
+  atomicAdd(&g_walk_stats[ANY ? 1 : 0][10], (unsigned long long)st.n_spill_push);
+  atomicAdd(&g_walk_stats[ANY ? 1 : 0][11], (unsigned long long)st.n_spill_pop);
+  atomicAdd(&g_walk_stats[ANY ? 1 : 0][12], (unsigned long long)st.n_slow);
 #endif
 }
 

@@ -66,10 +66,10 @@ __device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, floa
     float deltaE = S.g1 * maxE;
     float deltaS1 = 2 * (S.g2 * maxD * maxE + deltaE * maxD);
     float deltaS = S.g1 * maxP1;
-    float maxS = maxcomp(vabs(s));
-    float maxS1 = maxcomp(vabs(s1));
+    float maxS = maxabs3(s);
+    float maxS1 = maxabs3(s1);
     float deltaS2 = 2 * (S.g2 * maxS * maxS1 + deltaS * maxS1 + deltaS1 * maxS);
-    float maxS2 = maxcomp(vabs(s2));
+    float maxS2 = maxabs3(s2);
     float deltaT = 2 * (S.g2 * maxE * maxS2 + deltaS2 * maxE + deltaE * maxS2) * fabsf(inv);
     float tt = dot(e2, s2) * inv;
     if (tt < tmin + deltaT || tt > tmax) return false;
@@ -151,6 +151,9 @@ struct Stack {
   int sp;
   int ctx = 0;   // k_trace keeps two rays per lane: which of the lane's two stacks this is (rows ctx * kLdsDepth of
                  // `lds`, rows ctx * kSpillDepth of the spill column)
+#ifdef CASTER_WALK_STATS
+  uint32_t n_pop_iters = 0, n_pop_calls = 0, n_spill_push = 0, n_spill_pop = 0, n_slow = 0;   // tuning aid, per lane
+#endif
 };
 #ifndef CASTER_STACK_SPLIT
 #define CASTER_STACK_SPLIT 1
@@ -174,8 +177,12 @@ __device__ inline uint2 lds_get(Stack& s, int sp, uint32_t lane) { return s.lds[
 __device__ inline bool stack_push(Stack& s, uint32_t lane, int ref, float tn) {
   uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
   if (s.sp < kLdsDepth) lds_put(s, s.sp, lane, e);
-  else if (s.sp < kLdsDepth + kSpillDepth) s.spill[(size_t)(s.ctx * kSpillDepth + s.sp - kLdsDepth) * s.stride] = e;
-  else return false;
+  else if (s.sp < kLdsDepth + kSpillDepth) {
+    s.spill[(size_t)(s.ctx * kSpillDepth + s.sp - kLdsDepth) * s.stride] = e;
+#ifdef CASTER_WALK_STATS
+    ++s.n_spill_push;
+#endif
+  } else return false;
   ++s.sp;
   return true;
 }
@@ -184,14 +191,48 @@ __device__ inline bool stack_push(Stack& s, uint32_t lane, int ref, float tn) {
 // reference makes when it reaches that node (pathtracer.cu:231-232,
 // bbox.h:95).  kRefEmpty when nothing is left.
 __device__ inline int stack_next(Stack& s, uint32_t lane, float tmax) {
+#ifdef CASTER_WALK_STATS
+  ++s.n_pop_calls;
+#endif
   while (s.sp > 0) {
     --s.sp;
     uint2 e;
+#ifdef CASTER_WALK_STATS
+    ++s.n_pop_iters;
+    if (s.sp >= kLdsDepth) ++s.n_spill_pop;
+#endif
     if (s.sp < kLdsDepth) e = lds_get(s, s.sp, lane);
     else e = s.spill[(size_t)(s.ctx * kSpillDepth + s.sp - kLdsDepth) * s.stride];
     if (!(__uint_as_float(e.y) > tmax * fps::kNearCullSlack)) return (int)e.x;  // the slab test's own cull, with the ray's present tmax
   }
   return kRefEmpty;
+}
+
+// Occlusion rays keep no entry distances (their tmax never shrinks: a box that passed the test once would pass it
+// again), so their stack entries are bare references: 4 bytes, and the same LDS holds twice as many of them before
+// the column in HBM is needed.  Rows of 64 x 4 bytes, one conflict-free ds_write_b32 / ds_read_b32 per access.
+constexpr int kLdsDepthRefs = 2 * kLdsDepth;
+typedef __attribute__((address_space(3))) volatile uint32_t lds_u32_t;
+__device__ inline lds_u32_t* lds_ref_slot(Stack& s, int sp, uint32_t lane) {
+  return (lds_u32_t*)&s.lds[s.ctx * kLdsDepth][0] + (sp * kWave + (int)lane);
+}
+__device__ inline bool stack_push_ref(Stack& s, uint32_t lane, int ref) {
+  if (s.sp < kLdsDepthRefs) *lds_ref_slot(s, s.sp, lane) = (uint32_t)ref;
+  else if (s.sp < kLdsDepthRefs + kSpillDepth) s.spill[(size_t)(s.ctx * kSpillDepth + s.sp - kLdsDepthRefs) * s.stride] = make_uint2((uint32_t)ref, 0u);
+  else return false;
+  ++s.sp;
+  return true;
+}
+__device__ inline int stack_pop_ref(Stack& s, uint32_t lane) {
+  if (s.sp <= 0) return kRefEmpty;
+  --s.sp;
+  if (s.sp < kLdsDepthRefs) return (int)*lds_ref_slot(s, s.sp, lane);
+  return (int)s.spill[(size_t)(s.ctx * kSpillDepth + s.sp - kLdsDepthRefs) * s.stride].x;
+}
+// The next deferred child of a ray whose stack holds (reference, entry distance) pairs (KEYS) or bare references.
+template <bool KEYS>
+__device__ inline int stack_next_of(Stack& s, uint32_t lane, float tmax) {
+  return KEYS ? stack_next(s, lane, tmax) : stack_pop_ref(s, lane);
 }
 
 // One 4-wide node: four slab tests, the children that pass sorted nearest
@@ -227,7 +268,7 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
   bool h2 = box_test(v3(lx.z, ly.z, lz.z), v3(hx.z, hy.z, hz.z), o, inv, tmax, S.box_scale, k2) && r2 != kRefEmpty;
   bool h3 = box_test(v3(lx.w, ly.w, lz.w), v3(hx.w, hy.w, hz.w), o, inv, tmax, S.box_scale, k3) && r3 != kRefEmpty;
   int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-  if (nh == 0) return stack_next(st, lane, tmax);
+  if (nh == 0) return stack_next_of<SORT>(st, lane, tmax);
 #if CASTER_BRANCHY_NODE
   k0 = h0 ? k0 : INFINITY; k1 = h1 ? k1 : INFINITY; k2 = h2 ? k2 : INFINITY; k3 = h3 ? k3 : INFINITY;
 #define CASTER_CSWAP(ka, ra, kb, rb)        \
@@ -268,7 +309,7 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
   if (!SORT) {
     // An occlusion ray: its tmax never shrinks, so the order in which boxes are visited decides nothing and a
     // deferred box that passed the test once would pass it again -- the children that are hit are moved to the
-    // front by a five-exchange network on the hit flags (selects, no branch), no entry distances are kept.
+    // front by a five-exchange network on the hit flags (selects, no branch), and the stack holds bare references.
 #define CASTER_CMOVE(ha, ra, hb, rb)                     \
     {                                                     \
       const bool c_ = !ha && hb;                          \
@@ -282,16 +323,16 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
     CASTER_CMOVE(h1, r1, h3, r3)
     CASTER_CMOVE(h1, r1, h2, r2)
 #undef CASTER_CMOVE
-    if (st.sp + 3 <= kLdsDepth) {
-      lds_put(st, st.sp, lane, make_uint2((uint32_t)r1, 0u));
-      lds_put(st, st.sp + 1, lane, make_uint2((uint32_t)r2, 0u));
-      lds_put(st, st.sp + 2, lane, make_uint2((uint32_t)r3, 0u));
+    if (st.sp + 3 <= kLdsDepthRefs) {
+      *lds_ref_slot(st, st.sp, lane) = (uint32_t)r1;
+      *lds_ref_slot(st, st.sp + 1, lane) = (uint32_t)r2;
+      *lds_ref_slot(st, st.sp + 2, lane) = (uint32_t)r3;
       st.sp += nh - 1;
     } else {
       bool ok = true;
-      if (nh > 1) ok &= stack_push(st, lane, r1, 0.f);
-      if (nh > 2) ok &= stack_push(st, lane, r2, 0.f);
-      if (nh > 3) ok &= stack_push(st, lane, r3, 0.f);
+      if (nh > 1) ok &= stack_push_ref(st, lane, r1);
+      if (nh > 2) ok &= stack_push_ref(st, lane, r2);
+      if (nh > 3) ok &= stack_push_ref(st, lane, r3);
       if (!ok) atomicAdd(overflow, 1ull);
     }
     return r0;
@@ -326,6 +367,9 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
     lds_put(st, st.sp + 2, lane, make_uint2((uint32_t)r2, __float_as_uint(k2)));
     st.sp += nh - 1;
   } else {
+#ifdef CASTER_WALK_STATS
+    ++st.n_slow;
+#endif
     bool ok = true;
     if (nh > 1) ok &= stack_push(st, lane, r0, k0);
     if (nh > 2) ok &= stack_push(st, lane, r1, k1);
@@ -359,7 +403,7 @@ __device__ inline bool traverse(const DevScene& S, V3 o, V3 d, float tmin, float
                                 unsigned long long* overflow) {
   const uint32_t lane = threadIdx.x & 63u;
   V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
-  float maxD = maxcomp(vabs(d));
+  float maxD = maxabs3(d);
   hit.prim = -1;
   hit.t = tmax;
   hit.b1 = hit.b2 = 0.f;

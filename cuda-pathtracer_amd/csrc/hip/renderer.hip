@@ -1402,10 +1402,10 @@ int caster_iters_in_flight(const caster_renderer* r) { return r ? r->iters_in_fl
 
 #ifdef CASTER_WALK_STATS
 // tuning builds only: copies and clears the k_trace step counters
-int caster_debug_walk_stats(unsigned long long* out16) {
+int caster_debug_walk_stats(unsigned long long* out32) {
   HIPCHECK(hipDeviceSynchronize());
-  HIPCHECK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_walk_stats), 16 * sizeof(unsigned long long)));
-  unsigned long long zero[16] = {0};
+  HIPCHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_walk_stats), 32 * sizeof(unsigned long long)));
+  unsigned long long zero[32] = {0};
   HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stats), zero, sizeof(zero)));
   return CASTER_OK;
 }
