@@ -60,7 +60,7 @@ _lib = None
 # every symbol include/caster.h declares
 EXPORTS = [
     "caster_scene_load", "caster_scene_load_device", "caster_scene_get_bvh", "caster_scene_free", "caster_scene_get_info", "caster_begin", "caster_begin_streams", "caster_begin_multi",
-    "caster_set_rows", "caster_set_row_stripes",
+    "caster_set_rows", "caster_set_row_stripes", "caster_set_lookahead",
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
     "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_trace_rays_static", "caster_eval_function", "caster_get_stats", "caster_get_walk_counts", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
@@ -108,6 +108,7 @@ def lib():
         L.caster_begin_streams.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.caster_begin_multi.argtypes = [vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
         L.caster_set_rows.argtypes = [vp, C.c_int, C.c_int]
+        L.caster_set_lookahead.argtypes = [vp, C.c_int]
         L.caster_set_row_stripes.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.caster_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
         L.caster_render_async.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int]
@@ -210,6 +211,10 @@ class Renderer:
 
     def render(self, first_iter, n_iter=1, reset=False):
         _check(lib().caster_render(self._h, first_iter, n_iter, 1 if reset else 0))
+
+    def set_lookahead(self, n_iter):
+        """One-iteration calls trace ``n_iter`` iterations together and add them to the film one call at a time."""
+        _check(lib().caster_set_lookahead(self._h, n_iter))
 
     def render_async(self, first_iter, n_iter=1, reset=False):
         _check(lib().caster_render_async(self._h, first_iter, n_iter, 1 if reset else 0))
@@ -318,11 +323,12 @@ def write_image(path, image):
 _current = None
 
 
-def BeginRender(scene, width=None, height=None, epsilon=None, device=0, iters_in_flight=0):
+def BeginRender(scene, width=None, height=None, epsilon=None, device=0, iters_in_flight=0, lookahead=0):
     """``BeginRender(scene, w, h, eps)``: uploads the scene.  ``width``, ``height`` and
     ``epsilon`` are accepted for signature compatibility and must match the scene's own
     (the reference always passes ``config.width/height/epsilon`` back in,
-    CudaRender.cpp:37)."""
+    CudaRender.cpp:37).  ``lookahead`` > 1: ``Render`` calls for consecutive iterations are
+    traced that many at a time (``caster_set_lookahead``)."""
     global _current
     if width is not None and (width != scene.width or height != scene.height):
         raise CasterError(1, "BeginRender: width/height differ from the scene's")
@@ -330,7 +336,9 @@ def BeginRender(scene, width=None, height=None, epsilon=None, device=0, iters_in
         raise CasterError(1, "BeginRender: epsilon differs from the scene's")
     if _current is not None:
         _current.close()
-    _current = Renderer(scene, device, iters_in_flight)
+    _current = Renderer(scene, device, max(iters_in_flight, lookahead), 1 if lookahead > 1 else 0)
+    if lookahead > 1 and scene.integrator not in (3, 4):   # (light tracing and BDPT add to the film while they trace)
+        _current.set_lookahead(lookahead)
     return _current
 
 

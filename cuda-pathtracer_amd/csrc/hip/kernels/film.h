@@ -8,8 +8,10 @@ namespace caster {
 // Ends every path of the batch and accumulates the film as Output() does
 // (pathtracer.cu:2502-2513): acc += colour of iteration first..first+n-1, in
 // iteration order.  A NaN/Inf sample adds nothing.  One thread per pixel, so
-// the sum order is fixed.
-__global__ void k_finish(LaunchCtx L, float* acc, uint32_t n_iter) {
+// the sum order is fixed.  Only iterations k0 .. k1-1 of the batch's n_iter are
+// added (all of them, but for a batch that was traced ahead of the calls that
+// ask for its iterations one by one).
+__global__ void k_finish(LaunchCtx L, float* acc, uint32_t n_iter, uint32_t k0, uint32_t k1) {
   const DevScene& S = L.S;
   uint32_t npix = (uint32_t)S.width * (uint32_t)(S.row_y1 - S.row_y0);
   uint32_t invalid = 0;
@@ -19,7 +21,7 @@ __global__ void k_finish(LaunchCtx L, float* acc, uint32_t n_iter) {
     uint32_t local = pixel_slot(S, px, py);
     uint32_t pixel = px + py * (uint32_t)S.width;
     V3 a = v3(acc[3 * pixel], acc[3 * pixel + 1], acc[3 * pixel + 2]);
-    for (uint32_t k = 0; k < n_iter; ++k) {
+    for (uint32_t k = k0; k < k1; ++k) {
       uint32_t slot = batch_slot(S, k, local, n_iter);
       float4 lf = L.P.li_flags[slot];
       V3 Li = v3(lf);

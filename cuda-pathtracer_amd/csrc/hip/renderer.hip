@@ -352,6 +352,12 @@ struct caster_renderer {
   int batch_iters = 1;       // iterations per batch: the path pool holds iters_in_flight iterations of the whole image,
                              // and more of a part of it
   int n_cu = 256;
+  // Iterations traced ahead of the calls that ask for them one at a time (caster_set_lookahead): a batch of
+  // `ahead_n` iterations from `ahead_first` sits finished-but-not-accumulated in lane `ahead_lane`'s pool, and
+  // `ahead_done` of them have been added to the film.
+  int lookahead = 0;
+  int ahead_lane = -1;
+  uint32_t ahead_first = 0, ahead_n = 0, ahead_done = 0;
   // optional per-kernel-class timing with HIP events on the render streams
   bool profiling = false;
   struct Timed { int cls; hipEvent_t a, b; };
@@ -635,7 +641,8 @@ static void collect_timers(caster_renderer* r) {
 // the host; `tail` true (same lane, after the heads of the other lanes have been submitted, so
 // that they run meanwhile) submits what does -- the volumetric integrator's extra rounds, whose
 // number depends on a queue length -- and the film accumulation.
-static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t first, uint32_t n) {
+static int finish_iterations(caster_renderer* r, uint32_t lane, uint32_t n, uint32_t k0, uint32_t k1);
+static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t first, uint32_t n, bool finish = true) {
   const DevScene& S = r->S;
   Lane& ln = r->lanes[lane];
   if (tail) { first = ln.batch_first; n = ln.batch_n; }
@@ -817,11 +824,19 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
     HIPCHECK(hipGetLastError());
     return CASTER_OK;
   }
+  HIPCHECK(hipGetLastError());
+  return finish ? finish_iterations(r, lane, n, 0, n) : CASTER_OK;
+}
+
+// Adds iterations k0 .. k1-1 of the batch of `n` that lane `lane` has traced to the film.
+static int finish_iterations(caster_renderer* r, uint32_t lane, uint32_t n, uint32_t k0, uint32_t k1) {
+  Lane& ln = r->lanes[lane];
+  hipStream_t st = ln.stream;
   // a pixel's samples are added in iteration order whatever stream traced them
   if (r->last_finish && r->last_finish != ln.finish_done) HIPCHECK(hipStreamWaitEvent(st, r->last_finish, 0));
   {
     ScopedTimer t(r, st, CASTER_K_FINISH);
-    hipLaunchKernelGGL(k_finish, dim3(r->n_cu * 8), dim3(256), 0, st, L, r->acc, n);
+    hipLaunchKernelGGL(k_finish, dim3(r->n_cu * 8), dim3(256), 0, st, ctx_of(r, ln), r->acc, n, k0, k1);
   }
   HIPCHECK(hipEventRecord(ln.finish_done, st));
   r->last_finish = ln.finish_done;
@@ -976,6 +991,7 @@ int caster_set_row_stripes(caster_renderer* r, int y0, int y1, int rows, int str
   if (!r || y0 < 0 || y1 > r->S.height || y0 > y1 || rows < 1 || stride < rows)
     return fail(CASTER_ERR_ARG, "caster_set_row_stripes: bad row set");
   HIPCHECK(hipSetDevice(r->device));
+  r->ahead_lane = -1;   // (a window traced ahead lives in the pools this call rewrites)
   int rc = sync_lanes(r);   // batches under way were laid out for the previous row set
   if (rc) return rc;
   DevScene& S = r->S;
@@ -1024,8 +1040,30 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
     HIPCHECK(hipStreamSynchronize(r->lanes[0].stream));
     r->iterations = 0;
   }
-  uint32_t done = 0;
   const uint32_t n_lanes = (uint32_t)r->lanes.size();
+  // One iteration per call with a look-ahead window: the window's iterations are traced together the first
+  // time one of them is asked for, and each call adds its own iteration to the film.
+  const bool splats = r->S.integrator == IT_LT || r->S.integrator == IT_BDPT;
+  const bool look = r->lookahead > 1 && n_iter == 1 && !splats;
+  if (r->ahead_lane >= 0 && (!look || reset || first_iter != r->ahead_first + r->ahead_done)) r->ahead_lane = -1;
+  if (look) {
+    if (r->ahead_lane < 0) {
+      const uint32_t n = (uint32_t)std::min(r->lookahead, r->batch_iters);
+      const uint32_t lane = r->next_lane;
+      int rc = enqueue_batch(r, lane, false, first_iter, n);
+      if (!rc) rc = enqueue_batch(r, lane, true, 0, 0, false);
+      if (rc) return rc;
+      r->next_lane = (r->next_lane + 1) % n_lanes;
+      r->ahead_lane = (int)lane; r->ahead_first = first_iter; r->ahead_n = n; r->ahead_done = 0;
+    }
+    int rc = finish_iterations(r, (uint32_t)r->ahead_lane, r->ahead_n, r->ahead_done, r->ahead_done + 1);
+    if (rc) return rc;
+    if (++r->ahead_done == r->ahead_n) r->ahead_lane = -1;
+    r->iterations += 1;
+    r->samples += (uint64_t)r->live_pixels;
+    return CASTER_OK;
+  }
+  uint32_t done = 0;
   while (done < n_iter) {
     // one batch per stream: first what needs no host round trip, then the rest in batch order
     uint32_t heads = 0;
@@ -1043,6 +1081,14 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
   }
   r->iterations += n_iter;
   r->samples += (uint64_t)r->live_pixels * n_iter;
+  return CASTER_OK;
+}
+
+int caster_set_lookahead(caster_renderer* r, int n_iter) {
+  if (!r || n_iter < 0) return fail(CASTER_ERR_ARG, "caster_set_lookahead: bad argument");
+  if (!r->parts.empty()) return for_each_part(r, [&](int i) { return caster_set_lookahead(r->parts[(size_t)i], n_iter); });
+  r->lookahead = n_iter;
+  r->ahead_lane = -1;
   return CASTER_OK;
 }
 
@@ -1165,6 +1211,7 @@ int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
   if (!r || !ids) return fail(CASTER_ERR_ARG, "caster_primary_ids: null argument");
   if (!r->parts.empty()) return caster_primary_ids(r->parts[0], iter, ids);
   HIPCHECK(hipSetDevice(r->device));
+  r->ahead_lane = -1;   // (a window traced ahead lives in the pools this call rewrites)
   int rc = sync_lanes(r);
   if (rc) return rc;
   Lane& ln = r->lanes[0];
@@ -1201,6 +1248,7 @@ int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, cons
   if (n > cap) return fail(CASTER_ERR_ARG, "caster_trace_rays: more rays than the renderer has path slots");
   if (n == 0) return CASTER_OK;
   HIPCHECK(hipSetDevice(r->device));
+  r->ahead_lane = -1;   // (a window traced ahead lives in the pools this call rewrites)
   int rc = sync_lanes(r);
   if (rc) return rc;
   Lane& ln = r->lanes[0];

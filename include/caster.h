@@ -134,6 +134,18 @@ int caster_render(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int 
 int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter, int reset);
 int caster_sync(caster_renderer* r);
 
+/* For the caller the reference has: CudaRender::renderImage asks for ONE iteration per frame, iteration
+   numbers counting up (CudaRender.cpp:44-60), and a batch of one iteration leaves the GPU mostly idle.  With a
+   look-ahead of n_iter > 1 a caster_render(r, i, 1, 0) call traces iterations i .. i+n_iter-1 together (at most
+   the renderer's iterations in flight) and adds only iteration i to the film; the calls for i+1, i+2, ... then
+   find their iteration traced and only add it, so the film after every call is what it would be without the
+   look-ahead, bit for bit (a sample depends on its pixel and iteration alone, pathtracer.cu:881, and the film is
+   accumulated in iteration order).  A call that does not continue the sequence (another iteration number, more
+   than one iteration, reset, a change of the row set, a parity hook that uses the pools) drops what was traced
+   ahead.  The ray counts of caster_get_stats include iterations traced ahead.  0 or 1 turns it off (the
+   default).  Not for the splatting integrators (lt, bdpt), which add to the film while they trace. */
+int caster_set_lookahead(caster_renderer* r, int n_iter);
+
 /* Replaces Output + the D2H copy (pathtracer.cu:2502-2517,
    CudaRender.cpp:55).  mode 0: linear mean (sum / iterations rendered);
    mode 1: tonemapped as Output does (filmic or gamma per the scene's camera);

@@ -354,3 +354,45 @@ def test_several_devices_behind_one_handle(caster, key):
     assert g.iterations == spp and g.stats()["samples"] == st1["samples"]
     g.close()
     assert rel_rmse(got, want) <= 1e-5
+
+
+@pytest.mark.parametrize("key", ["cornell_ao", "stairs_pt", "cornell_vpt"])
+def test_one_iteration_calls_with_a_lookahead_window(caster, key):
+    """caster_set_lookahead: calls for one iteration each trace a window of iterations together and add them to the
+    film one call at a time.  The film after EVERY call equals the film of a renderer without the window, bit for
+    bit; a call that breaks the sequence (a skipped iteration, a reset, several iterations at once, a parity hook in
+    between) drops the window and still gives the right film."""
+    sc = caster.Scene(os.path.join(GOLD, "scenes", key, "scene.json"))
+    plain = caster.Renderer(sc, 0, 1, 1)
+    ahead = caster.Renderer(sc, 0, 8, 2)
+    ahead.set_lookahead(5)
+    for it in range(1, 13):                       # windows 1-5, 6-10, 11-15 (the last one left unfinished)
+        plain.render(it, 1, it == 1)
+        ahead.render(it, 1, it == 1)
+        np.testing.assert_array_equal(ahead.read_film(2), plain.read_film(2), err_msg="%s iteration %d" % (key, it))
+        assert ahead.iterations == it
+    np.testing.assert_array_equal(ahead.read_film(1), plain.read_film(1))
+    assert ahead.stats()["samples"] == plain.stats()["samples"] and ahead.stats()["invalid"] == plain.stats()["invalid"]
+    assert ahead.stats()["rays"][0] > plain.stats()["rays"][0]          # iterations 13-15 were traced and not used
+    # a jump, a parity hook between two calls, several iterations in one call, then single calls again
+    ids = plain.primary_ids(1)
+    for first, n in ((20, 1), (21, 1), ("ids", 0), (22, 1), (23, 3), (26, 1), (27, 1)):
+        if first == "ids":
+            np.testing.assert_array_equal(ahead.primary_ids(1), ids)
+            continue
+        plain.render(first, n, False)
+        ahead.render(first, n, False)
+        np.testing.assert_array_equal(ahead.read_film(2), plain.read_film(2), err_msg="%s after %d+%d" % (key, first, n))
+    # reset in the middle of a window
+    plain.render(1, 1, True)
+    ahead.render(1, 1, True)
+    np.testing.assert_array_equal(ahead.read_film(2), plain.read_film(2))
+    # the reference-shaped calls
+    caster.BeginRender(sc, sc.width, sc.height, sc.info.epsilon, lookahead=4)
+    imgs = [caster.Render(sc, sc.width, sc.height, None, it, False) for it in range(1, 7)]
+    caster.EndRender()
+    for it in range(1, 7):
+        plain.render(it, 1, it == 1)
+        np.testing.assert_array_equal(imgs[it - 1], plain.read_film(1))
+    plain.close()
+    ahead.close()
