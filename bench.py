@@ -93,6 +93,23 @@ def pmc_traffic_per_launch(kernel):
         return None
 
 
+def pmc_secondary(kernel, n_simd=1024):
+    """What else the committed PMC passes say about `kernel` (per-dispatch averages): the share of the time its
+    SIMDs' vector ALUs were issuing (SQ_ACTIVE_INST_VALU over the wavefronts' lifetime per SIMD; the SQ counts in
+    units of four clocks, one wave64 instruction each), the lanes active in an issued vector instruction, the L2
+    hit rate and the wavefronts resident per SIMD.  None without the file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+            k = json.load(f)[kernel]
+        waves_per_simd = k["SQ_WAVES"]["avg"] / n_simd
+        return {"valu_issue_busy": k["SQ_ACTIVE_INST_VALU"]["avg"] / (k["SQ_WAVE_CYCLES"]["avg"] / waves_per_simd) ,
+                "valu_lane_utilisation": k["SQ_THREAD_CYCLES_VALU"]["avg"] / (64.0 * k["SQ_ACTIVE_INST_VALU"]["avg"]),
+                "l2_hit_rate": k["TCC_HIT_sum"]["avg"] / (k["TCC_HIT_sum"]["avg"] + k["TCC_MISS_sum"]["avg"]),
+                "waves_per_simd": waves_per_simd}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def launch_ranks(n, argv):
     """Runs this script under torch.distributed.run with `n` ranks on this node (one per GPU) as a
     child process and returns its exit status; the ranks' output passes through unchanged."""
@@ -364,6 +381,7 @@ def main():
                 # (the PMC passes ran the same command: launches of the same average size)
                 r["traffic_over_requested"] = r["traffic"] / r["requested_bytes_per_launch"]
                 r["hbm_frac"] = r["traffic"] * launches / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            r["pmc"] = pmc_secondary(sym)
             return r
 
         walk = r.walk_counts()
