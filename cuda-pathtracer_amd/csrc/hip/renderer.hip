@@ -1476,8 +1476,13 @@ static int for_each_part(caster_renderer* g, Fn fn) {
   th.reserve(n);
   for (size_t i = 0; i < n; ++i)
     th.emplace_back([&, i]() {
-      rc[i] = fn((int)i);
-      if (rc[i]) msg[i] = g_last_error;   // (the message is the worker thread's)
+      try {
+        rc[i] = fn((int)i);
+        if (rc[i]) msg[i] = g_last_error;   // (the message is the worker thread's)
+      } catch (const std::exception& e) {   // (nothing may leave a thread, or the C boundary)
+        rc[i] = CASTER_ERR_DEVICE;
+        msg[i] = e.what();
+      }
     });
   for (auto& t : th) t.join();
   for (size_t i = 0; i < n; ++i)
