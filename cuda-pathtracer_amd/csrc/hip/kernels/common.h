@@ -65,6 +65,10 @@ __device__ inline float length(V3 v) { return sqrtf(dot(v, v)); }
 __device__ inline V3 normalize(V3 v) { return v * fps::rsqrt_(dot(v, v)); }
 __device__ inline V3 vabs(V3 v) { return V3{fabsf(v.x), fabsf(v.y), fabsf(v.z)}; }
 __device__ inline float maxcomp(V3 a) { return fps::fmax_(fps::fmax_(a.x, a.y), a.z); }
+// The lanes of the wavefront for which `p` holds, as the compare's own result mask (HIP's __ballot takes an int:
+// the flag is first made a 0/1 number and then compared with zero again, two vector instructions per vote).
+__device__ inline unsigned long long lane_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ inline bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // maxcomp(vabs(a)) as one v_max3_f32 with |.| operands: among non-negative numbers the native maximum picks the value
 // fps::fmax_ picks (it drops a NaN operand as fmax_ does, and no zero here carries a sign).
 __device__ inline float maxabs3(V3 a) { return __builtin_fmaxf(__builtin_fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)); }

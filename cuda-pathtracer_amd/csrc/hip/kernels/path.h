@@ -24,7 +24,7 @@ struct StageArea {
 };
 __device__ inline void stage_push(const RayQueue& stage, uint32_t base, uint32_t& n, bool want, int slot, V3 o,
                                   int seed, V3 d, float tmax) {
-  unsigned long long mask = __ballot(want);
+  unsigned long long mask = lane_ballot(want);
   if (mask == 0) return;
   uint32_t lane = threadIdx.x & 63u;
   if (want) {
@@ -310,7 +310,7 @@ __device__ inline void shade_pt_vertices(const LaunchCtx& L, const RayQueue& cur
   // emitter's index where a shadow ray carries -1.
   if (PROBE_ANY) {
     stage_push(stage.shadow, sc.base_shadow, sc.n_shadow, want_probe, slot, po, pseed, pd, ptmax);
-    sc.n_probe += (uint32_t)__popcll(__ballot(want_probe));
+    sc.n_probe += (uint32_t)__popcll(lane_ballot(want_probe));
   } else {
     stage_push(stage.probe, sc.base, sc.n_probe, want_probe, slot, po, pseed, pd, ptmax);
   }
@@ -357,11 +357,11 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
         if (prim >= 0) cls = CASTER_SHADE_SORT ? __float_as_int(S.shade[(size_t)prim * kShadeF4 + 7].y) : 0;
         else if (env && cur.d[idx].w >= 0.f) cls = CASTER_SHADE_SORT ? 6 : 0;   // (tmax < 0: a slot outside the image)
       }
-      unsigned long long todo = __ballot(cls >= 0);
+      unsigned long long todo = lane_ballot(cls >= 0);
       while (todo) {
         int first = __builtin_ctzll(todo);
         int c = __builtin_amdgcn_readlane(cls, first);
-        unsigned long long mine = __ballot(cls == c);
+        unsigned long long mine = lane_ballot(cls == c);
         uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)q_head, c);
         uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)q_len, c);
         if (cls == c)
@@ -370,12 +370,12 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_pt(LaunchCt
         todo &= ~mine;
       }
       __syncthreads();
-      unsigned long long full = __ballot(lane < (uint32_t)kShadeLists && q_len >= (uint32_t)kWave);
+      unsigned long long full = lane_ballot(lane < (uint32_t)kShadeLists && q_len >= (uint32_t)kWave);
       while (full) {
         int c = __builtin_ctzll(full);
         uint32_t my = take_group(c, kWave);
         shade_pt_vertices<PROBE_ANY>(L, cur, stage, sc, my, true);
-        full = __ballot(lane < (uint32_t)kShadeLists && q_len >= (uint32_t)kWave);
+        full = lane_ballot(lane < (uint32_t)kShadeLists && q_len >= (uint32_t)kWave);
       }
       __syncthreads();
     }

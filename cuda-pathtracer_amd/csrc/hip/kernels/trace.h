@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
   };
   // Gives the lanes whose slot `r` is free the next unclaimed rays.
   auto refill = [&](WalkRay& r) {
-    unsigned long long idle_mask = __ballot(r.idx < 0);
+    unsigned long long idle_mask = lane_ballot(r.idx < 0);
     uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     if (!more || n_idle == 0) return;
     if (chunk_next == chunk_end) {
@@ -268,13 +268,13 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
     retire(a);
     if (kTraceRays == 2) retire(b);
     // free slots are refilled once there are enough of them
-    uint32_t n_idle = (uint32_t)__popcll(__ballot(a.idx < 0)) + (kTraceRays == 2 ? (uint32_t)__popcll(__ballot(b.idx < 0)) : 0u);
+    uint32_t n_idle = (uint32_t)__popcll(lane_ballot(a.idx < 0)) + (kTraceRays == 2 ? (uint32_t)__popcll(lane_ballot(b.idx < 0)) : 0u);
     if (more && n_idle >= (uint32_t)kRefill) {
       refill(a);
       if (kTraceRays == 2) refill(b);
     }
     CASTER_WS(6, 1);
-    if (!__any(a.idx >= 0 || b.idx >= 0)) {
+    if (!any_lane(a.idx >= 0 || b.idx >= 0)) {
       if (!more) break;
       continue;
     }
@@ -289,21 +289,23 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
     for (;;) {
       const bool node_a = a.cur >= 0, node_b = kTraceRays == 2 && b.cur >= 0;
       const bool leaf_a = a.pend != kRefEmpty, leaf_b = kTraceRays == 2 && b.pend != kRefEmpty;
-      const int n_inner = __popcll(__ballot(node_a || node_b)), n_leaf = __popcll(__ballot(leaf_a || leaf_b));
-      const int n_busy = __popcll(__ballot(a.cur != kRefEmpty || a.pend != kRefEmpty)) +
-                         (kTraceRays == 2 ? __popcll(__ballot(b.cur != kRefEmpty || b.pend != kRefEmpty)) : 0);
+      const int n_inner = __popcll(lane_ballot(node_a || node_b)), n_leaf = __popcll(lane_ballot(leaf_a || leaf_b));
+      // (votes on single compares and the masks combined as scalars: the vote on an `or` of two flags is made
+      // a number per lane and compared again)
+      const int n_busy = __popcll(lane_ballot(a.cur != kRefEmpty) | lane_ballot(a.pend != kRefEmpty)) +
+                         (kTraceRays == 2 ? __popcll(lane_ballot(b.cur != kRefEmpty) | lane_ballot(b.pend != kRefEmpty)) : 0);
       if (n_busy == 0) break;
       if (more && kTraceRays * kWave - n_busy >= kRefill) break;
       CASTER_WS(4, n_busy);
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
         CASTER_WS(0, 1);
         CASTER_WS(1, n_inner);
-        CASTER_WS(5, __any(a.cur >= 0 && a.sp + 3 > kLdsDepth) ? 1 : 0);
-        CASTER_WS(7, __popcll(__ballot(a.cur >= 0)) * 0 + __popcll(__ballot(a.cur >= 0 && a.sp + 3 > kLdsDepth)));
+        CASTER_WS(5, any_lane(a.cur >= 0 && a.sp + 3 > kLdsDepth) ? 1 : 0);
+        CASTER_WS(7, __popcll(lane_ballot(a.cur >= 0)) * 0 + __popcll(lane_ballot(a.cur >= 0 && a.sp + 3 > kLdsDepth)));
         // the lane's first ray if it stands at a node, else its second
         const bool w = kTraceRays == 2 && !node_a;
         int cur = pick(w, a.cur, b.cur);
-        n_node_fetches += (uint32_t)__popcll(__ballot(cur >= n_top));
+        n_node_fetches += (uint32_t)__popcll(lane_ballot(cur >= n_top));
         if (cur >= 0) {
           const V3 o = pick(w, a.o, b.o), inv = pick(w, a.inv, b.inv);
           const float tmax = pick(w, a.hit.t, b.hit.t);
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
         CASTER_WS(3, n_leaf);
         const bool w = kTraceRays == 2 && !leaf_a;
         int pend = pick(w, a.pend, b.pend);
-        n_prim_tests += (uint32_t)__popcll(__ballot(pend != kRefEmpty));
+        n_prim_tests += (uint32_t)n_leaf;   // (every lane that holds a leaf tests one primitive)
         if (pend != kRefEmpty) {
           const V3 o = pick(w, a.o, b.o), d = pick(w, a.d, b.d);
           const float maxD = pick(w, a.maxD, b.maxD);

@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 
 # key -> (generator scene, detail, width, height, maxDepth, samples per pixel)
 FRAMES = {
+    "C1_cornell_ao_512": ("cornell_ao", 1.0, 512, 512, 8, 16),      # 4.2e6 samples: the whole of configuration 1
+    "C2_knot_1024": ("knot_pt", 1.0, 1024, 1024, 8, 8),             # 8.4e6 samples; glass, mirror, checker texture
     "C3_stairs_1080p": ("stairs_pt", 1.0, 1920, 1080, 8, 16),     # 3.3e7 samples; lines and spheres on the railing
     "C4_cornell_fog_1024": ("cornell_vpt", 1.0, 1024, 1024, 16, 8),  # 8.4e6 samples; spheres inside the medium
     "C5_car_1080p": ("car_pt", 1.0, 1920, 1080, 8, 4),             # 8.3e6 samples; 1.37 M primitives

@@ -10,6 +10,6 @@ import json
 d = json.load(open('gpurun_out/bench_latest.json'))
 print('bench', round(d['value'], 1), 'one stream', d['roofline'].get('exclusive', {}).get('msamples_per_s'))
 for k in d['roofline']['exclusive'].get('kernels', []):
-    print('  excl', k['kernel'], 'ms/launch', round(k['ms_per_launch'], 3), 'frac', round(k['frac'], 3))
+    print('  excl', k['kernel'], 'ms/launch', round(k['avg_launch_ms'], 3), 'frac', round(k['frac'], 3))
 print('kernel_ms', {k: round(v, 1) for k, v in d['kernel_ms'].items()})
 PY
