@@ -288,8 +288,14 @@ def test_render_tool_previews_and_ranks(tmp_path):
     of the plain run, bit for bit on one GPU (the film adds its iterations in the same order); two ranks
     sharing the GPU (gloo, a rehearsal of the multi-GPU path) hand their films over at every preview and
     end on the same mean up to the order of the float additions."""
+    import socket
     import subprocess
     import sys
+
+    def free_port():
+        with socket.socket() as sock:   # (a port nobody holds right now: the box may be shared)
+            sock.bind(("127.0.0.1", 0))
+            return str(sock.getsockname()[1])
     key = sorted(VEC["scenes"])[0]
     scene = os.path.join(GOLD, "scenes", key, "scene.json")
     tool = os.path.join(ROOT, "tools", "render.py")
@@ -297,10 +303,10 @@ def test_render_tool_previews_and_ranks(tmp_path):
     for name, extra, launcher in (("plain", [], []), ("preview", ["--preview-every", "2"], []),
                                   ("ranks", ["--preview-every", "3", "--backend", "gloo", "--share-gpu"],
                                    ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                                    "--master-addr", "127.0.0.1", "--master-port", "29653"]),
+                                    "--master-addr", "127.0.0.1", "--master-port", free_port()]),
                                   ("tiles", ["--preview-every", "4", "--shard", "tile", "--backend", "gloo", "--share-gpu"],
                                    ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                                    "--master-addr", "127.0.0.1", "--master-port", "29654"])):
+                                    "--master-addr", "127.0.0.1", "--master-port", free_port()])):
         outs[name] = str(tmp_path / (name + ".pfm"))
         p = subprocess.run([sys.executable] + launcher + [tool, scene, "--spp", "7", "--iters-in-flight", "2", "--out", outs[name]] + extra,
                            capture_output=True, text=True, timeout=600)
