@@ -308,34 +308,27 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
 #else
   if (!SORT) {
     // An occlusion ray: its tmax never shrinks, so the order in which boxes are visited decides nothing and a
-    // deferred box that passed the test once would pass it again -- the children that are hit are moved to the
-    // front by a five-exchange network on the hit flags (selects, no branch), and the stack holds bare references.
-#define CASTER_CMOVE(ha, ra, hb, rb)                     \
-    {                                                     \
-      const bool c_ = !ha && hb;                          \
-      const int nra_ = c_ ? rb : ra, nrb_ = c_ ? ra : rb; \
-      const bool nha_ = ha || hb, nhb_ = ha && hb;        \
-      ra = nra_; rb = nrb_; ha = nha_; hb = nhb_;         \
-    }
-    CASTER_CMOVE(h0, r0, h1, r1)
-    CASTER_CMOVE(h2, r2, h3, r3)
-    CASTER_CMOVE(h0, r0, h2, r2)
-    CASTER_CMOVE(h1, r1, h3, r3)
-    CASTER_CMOVE(h1, r1, h2, r2)
-#undef CASTER_CMOVE
+    // deferred box that passed the test once would pass it again: no entry distances, no sorting, and the stack
+    // holds bare references.
+    // The first child that is hit is visited now, the other hit children are deferred: three stores, each at the
+    // height the ones before it left (a store whose child was not hit is overwritten by the next one, or lies
+    // beyond the top of the stack and is never read).
+    const int first = h0 ? r0 : (h1 ? r1 : (h2 ? r2 : r3));
+    const bool d1 = h1 && h0, d2 = h2 && (h0 || h1), d3 = h3 && (h0 || h1 || h2);
     if (st.sp + 3 <= kLdsDepthRefs) {
-      *lds_ref_slot(st, st.sp, lane) = (uint32_t)r1;
-      *lds_ref_slot(st, st.sp + 1, lane) = (uint32_t)r2;
-      *lds_ref_slot(st, st.sp + 2, lane) = (uint32_t)r3;
-      st.sp += nh - 1;
+      int sp = st.sp;
+      *lds_ref_slot(st, sp, lane) = (uint32_t)r1; sp += d1 ? 1 : 0;
+      *lds_ref_slot(st, sp, lane) = (uint32_t)r2; sp += d2 ? 1 : 0;
+      *lds_ref_slot(st, sp, lane) = (uint32_t)r3; sp += d3 ? 1 : 0;
+      st.sp = sp;
     } else {
       bool ok = true;
-      if (nh > 1) ok &= stack_push_ref(st, lane, r1);
-      if (nh > 2) ok &= stack_push_ref(st, lane, r2);
-      if (nh > 3) ok &= stack_push_ref(st, lane, r3);
+      if (d1) ok &= stack_push_ref(st, lane, r1);
+      if (d2) ok &= stack_push_ref(st, lane, r2);
+      if (d3) ok &= stack_push_ref(st, lane, r3);
       if (!ok) atomicAdd(overflow, 1ull);
     }
-    return r0;
+    return first;
   }
   // The children that are hit, farthest first, the misses behind them (their key is -infinity): a
   // five-exchange network written as selects, so that it costs five compares and twenty moves and
