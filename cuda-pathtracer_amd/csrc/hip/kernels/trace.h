@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
         int pend = pick(w, a.pend, b.pend);
         n_prim_tests += (uint32_t)n_leaf;   // (every lane that holds a leaf tests one primitive)
         if (pend != kRefEmpty) {
-          const V3 o = pick(w, a.o, b.o), d = pick(w, a.d, b.d);
+          const V3 o = pick(w, a.o, b.o), d = pick(w, a.d, b.d), inv = pick(w, a.inv, b.inv);
           const float maxD = pick(w, a.maxD, b.maxD);
           float ht = pick(w, a.hit.t, b.hit.t);
           const int hp = pick(w, a.hit.prim, b.hit.prim);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
           int i = ~pend;
           float t, b1, b2;
           bool last;
-          bool found = prim_test(S, i, o, d, maxD, tmin, ht, t, b1, b2, last);
+          bool found = prim_test(S, i, o, d, inv, maxD, tmin, ht, t, b1, b2, last);
           // (an occlusion ray holds -1 in hit.prim, or the emitter a probe ray was sent to, at
           // distance hit.t: the emitter itself and what it hides at equal distance do not occlude)
           const bool better = found && (t < ht || i > hp);

@@ -37,15 +37,24 @@ struct Hit {
 // edge vectors and coordinate maxima precomputed per primitive (the same
 // float operations, done once on the host).  Sphere: sphere.h:24-66.  Line:
 // line.h:33-72.
-__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, float maxD, float tmin,
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, V3 inv, float maxD, float tmin,
                                      float tmax, float& t, float& ob1, float& ob2, bool& last);
-__device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, float tmax,
+// (`inv` = 1 / d per component, which the walkers hold anyway: the sphere test wants it for its box)
+__device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, V3 inv, float maxD, float tmin, float tmax,
                                  float& t, float& ob1, float& ob2, bool& last) {
   const float4* rec = S.isect + (size_t)i * kIsectF4;
-  return prim_test_rec(S, rec[0], rec[1], rec[2], o, d, maxD, tmin, tmax, t, ob1, ob2, last);
+  return prim_test_rec(S, rec[0], rec[1], rec[2], o, d, inv, maxD, tmin, tmax, t, ob1, ob2, last);
+}
+__device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, float tmax,
+                                 float& t, float& ob1, float& ob2, bool& last) {
+  return prim_test(S, i, o, d, v3(1.f / d.x, 1.f / d.y, 1.f / d.z), maxD, tmin, tmax, t, ob1, ob2, last);
+}
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, float maxD, float tmin,
+                                     float tmax, float& t, float& ob1, float& ob2, bool& last) {
+  return prim_test_rec(S, a, b, c, o, d, v3(1.f / d.x, 1.f / d.y, 1.f / d.z), maxD, tmin, tmax, t, ob1, ob2, last);
 }
 // The same test on a record already in registers.
-__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, float maxD, float tmin,
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, V3 inv, float maxD, float tmin,
                                      float tmax, float& t, float& ob1, float& ob2, bool& last) {
   uint32_t bits = __float_as_uint(c.w);
   last = (bits & kPrimLastInLeaf) != 0;
@@ -106,7 +115,7 @@ __device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, floa
     // entry of every box above it, so it is tested whenever it could still win, whatever the
     // order the tree is walked in.
     float tn;
-    (void)box_test(v3(a) - radius, v3(a) + radius, o, v3(1.f / d.x, 1.f / d.y, 1.f / d.z), INFINITY, S.box_scale, tn);
+    (void)box_test(v3(a) - radius, v3(a) + radius, o, inv, INFINITY, S.box_scale, tn);
     if (tn > th * fps::kNearCullSlack) return false;
     t = th; ob1 = 0.f; ob2 = 0.f;
     return true;
