@@ -10,7 +10,8 @@ d = json.load(open('gpurun_out/v.json'))
 k = d['kernel_ms']
 ex = d.get('roofline', {}).get('exclusive', {})
 exk = ' '.join('%s %.2f' % (e['kernel'][:14], e['avg_launch_ms']) for e in ex.get('kernels', []))
-print('%-45s %7.1f Msamples/s  ext %.1f shade %.1f shadow %.1f probe %.1f | one stream %.1f Msamples/s, avg launch ms: %s' % (
-    sys.argv[1][-45:], d['value'], k['extend'], k['shade'], k['shadow'], k['probe'], ex.get('msamples_per_s', 0), exk))
+w = d.get('roofline', {}).get('gpu_walk', {})
+print('%-45s %7.1f Msamples/s  ext %.1f shade %.1f shadow %.1f probe %.1f | one stream %.1f Msamples/s, avg launch ms: %s | nodes/ray %.2f prims/ray %.2f' % (
+    sys.argv[1][-45:], d['value'], k['extend'], k['shade'], k['shadow'], k['probe'], ex.get('msamples_per_s', 0), exk, w.get('node_fetches_per_ray', 0), w.get('prim_tests_per_ray', 0)))
 PY
 done
