@@ -274,7 +274,7 @@ def main():
             "kernel_launches": {k: v[1] for k, v in kt.items()},
         }
         counts = None
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:   # (the CPU baseline belongs to the one-GPU line)
             import oracle_lib as ol
             o = ol.Oracle(path)
             # the oracle on this host's cores: as many threads as there are (64 at most), and one
@@ -396,8 +396,8 @@ def main():
                                "note": "launch durations of the timed region: several streams share the GPU"}}
         # one-stream repeat: each launch has the GPU to itself
         try:
-            if a.no_exclusive:
-                raise caster.CasterError(0, "skipped (--no-exclusive)")
+            if a.no_exclusive or world > 1:
+                raise caster.CasterError(0, "skipped (--no-exclusive, or several ranks: the other ranks would wait)")
             r1 = caster.Renderer(scene, dev_index, iters_in_flight, 1)
             if rows != (0, scene.height):
                 r1.set_row_stripes(*rows)
