@@ -110,6 +110,30 @@ def pmc_secondary(kernel, n_simd=1024):
         return None
 
 
+VALU_PEAK_PER_S = 1024 * 2.4e9 / 4.0   # wave64 vector instructions per second: 256 CUs x 4 SIMDs, one per four clocks, 2.4 GHz
+
+
+def valu_issue(kernel_launches, shade_name, steps, dt):
+    """The share of the chip's vector-instruction issue the timed region used: wave64 vector instructions per launch of
+    every kernel from the committed PMC passes of this same command (SQ_INSTS_VALU, profiles/r02_pmc.json) x the launches
+    of the timed region, over what 1024 SIMDs issue at one instruction per four clocks and the 2.4 GHz peak clock.  (The
+    chip holds about 2.0 GHz under this load, so the fraction of the issue slots there actually were is a fifth higher.)
+    None without the file, or for a command other than the profiled one (other kernels)."""
+    symbols = {"generate": "k_generate", "extend": "k_trace<false>", "shadow": "k_trace<true>", "shade": shade_name,
+               "finish": "k_finish"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+            pmc = json.load(f)
+        total = sum(pmc[sym]["SQ_INSTS_VALU"]["avg"] * kernel_launches.get(cat, 0) for cat, sym in symbols.items())
+    except (OSError, KeyError, ValueError):
+        return None
+    if kernel_launches.get("probe", 0) or dt <= 0:
+        return None
+    return {"bound": "valu", "wave_instructions_per_step": total / max(steps, 1), "achieved": total / dt / 1e9,
+            "peak": VALU_PEAK_PER_S / 1e9, "unit": "G wave64 vector instructions/s", "frac": total / dt / VALU_PEAK_PER_S,
+            "note": "all kernels of the timed region together; per-launch instruction counts of the committed PMC passes"}
+
+
 def launch_ranks(n, argv):
     """Runs this script under torch.distributed.run with `n` ranks on this node (one per GPU) as a
     child process and returns its exit status; the ranks' output passes through unchanged."""
@@ -390,7 +414,8 @@ def main():
         per_kernel = [roofline_of(sym, kt, st["rays"], walk, st["samples"]) for sym in symbols]
         # every launch of the timed region against the wall time: what the three kernels together asked for per second
         pipeline_req = sum(k["requested_bytes_per_launch"] * k["launches"] for k in per_kernel)
-        roof = {"overlapped": {"streams": r_streams, "kernels": per_kernel,
+        roof = {"valu_issue": valu_issue(out["kernel_launches"], shade_name, a.steps, dt) if world == 1 and a.scene == "car_pt" else None,
+                "overlapped": {"streams": r_streams, "kernels": per_kernel,
                                "requested_bytes_per_step": pipeline_req / max(a.steps, 1),
                                "requested_rate_gbs": pipeline_req / dt / 1e9,
                                "note": "launch durations of the timed region: several streams share the GPU"}}

@@ -582,6 +582,15 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     int by_lds = (160 * 1024) / lds_per_block * kTraceBlockWaves;
     int by_regs = CASTER_TRACE_WAVES * 4 / kTraceBlockWaves * kTraceBlockWaves;
     r->walk_grid = r->n_cu * std::max(kTraceBlockWaves, std::min(by_lds, by_regs));
+    // tuning knobs: fewer resident wavefronts per CU for the traversal / the shade kernels (never more than fit)
+    if (const char* e = getenv("CASTER_WALK_PER_CU")) {
+      int v = atoi(e) / kTraceBlockWaves * kTraceBlockWaves;
+      if (v >= kTraceBlockWaves && r->n_cu * v < r->walk_grid) r->walk_grid = r->n_cu * v;
+    }
+    if (const char* e = getenv("CASTER_SHADE_PER_CU")) {
+      int v = atoi(e);
+      if (v >= 1 && r->n_cu * v < r->shade_grid) r->shade_grid = r->n_cu * v;
+    }
   }
   r->work_init = 0;  // the work counters count from the end of k_trace's static assignment, whose size it derives from the queue length
   if (sc.integrator == IT_BDPT) {
