@@ -99,6 +99,9 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 //   ANY=false: closest hit; (t, prim, b1, b2) goes into the queue entry.
 //   ANY=true:  any hit; an occluded ray clears the pending light-sampled term
 //              of its path.
+#ifndef CASTER_OCTANT_BOXES
+#define CASTER_OCTANT_BOXES 1   // 1: the node step reads a ray's near and far planes by its direction octant (box_test_octant)
+#endif
 #ifndef CASTER_ANY_UNSORTED
 #define CASTER_ANY_UNSORTED 1
 #endif
@@ -126,11 +129,14 @@ struct WalkRay {
   int pend;  // a leaf waiting for its primitives to be tested (same encoding), kRefEmpty
   int sp;    // height of its stack
   int occluded;
+  Octant oct;  // direction octant (node_step<.., OCT>)
+  int plain;   // 1 / direction or the origin is not finite in some component: the ray keeps to the plain slab test
 };
 __device__ inline void walk_ray_idle(WalkRay& r) {
   r.o = v3(0, 0, 0); r.d = v3(0, 0, 1); r.inv = v3(0, 0, 1); r.maxD = 1.f;
   r.hit.t = 0.f; r.hit.prim = -1; r.hit.b1 = r.hit.b2 = 0.f;
   r.idx = -1; r.cur = kRefEmpty; r.pend = kRefEmpty; r.sp = 0; r.occluded = 0;
+  r.oct = Octant{0, 16, 32}; r.plain = 0;
 }
 __device__ inline float pick(bool second, float x0, float x1) { return second ? x1 : x0; }
 __device__ inline int pick(bool second, int x0, int x1) { return second ? x1 : x0; }
@@ -249,6 +255,9 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       r.o = v3(o4); r.d = v3(d4);
       r.inv = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
       r.maxD = maxabs3(r.d);
+      r.oct = octant_of(r.inv);
+      r.plain = !(fabsf(r.inv.x) < INFINITY && fabsf(r.inv.y) < INFINITY && fabsf(r.inv.z) < INFINITY &&
+                  fabsf(r.o.x) < INFINITY && fabsf(r.o.y) < INFINITY && fabsf(r.o.z) < INFINITY) ? 1 : 0;
       // every queued ray starts at the scene's epsilon; o.w carries a hit known
       // beforehand (a probe ray's nearest emitter, at distance tmax) or -1
       r.hit.t = d4.w; r.hit.prim = __float_as_int(o4.w); r.hit.b1 = r.hit.b2 = 0.f;
@@ -306,13 +315,17 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
         const bool w = kTraceRays == 2 && !node_a;
         int cur = pick(w, a.cur, b.cur);
         n_node_fetches += (uint32_t)__popcll(lane_ballot(cur >= n_top));
+        // (one ray in 10^7 is parallel to an axis; the whole step then takes the plain slab test)
+        const bool plain_step = !CASTER_OCTANT_BOXES || any_lane(cur >= 0 && (kTraceRays == 2 ? (a.plain | b.plain) : a.plain) != 0);
         if (cur >= 0) {
           const V3 o = pick(w, a.o, b.o), inv = pick(w, a.inv, b.inv);
           const float tmax = pick(w, a.hit.t, b.hit.t);
           int pend = pick(w, a.pend, b.pend);
           st.sp = pick(w, a.sp, b.sp);
           st.ctx = w ? 1 : 0;
-          cur = node_step<!ANY || !CASTER_ANY_UNSORTED>(S, cur, o, inv, tmax, st, lane, overflow, s_top, n_top);
+          if (plain_step) cur = node_step<!ANY || !CASTER_ANY_UNSORTED, false>(S, cur, o, inv, tmax, st, lane, overflow, s_top, n_top);
+          else cur = node_step<!ANY || !CASTER_ANY_UNSORTED, true>(S, cur, o, inv, tmax, st, lane, overflow, s_top, n_top,
+                                                                   kTraceRays == 2 && w ? b.oct : a.oct);
           if (cur < 0 && cur != kRefEmpty && pend == kRefEmpty) {
             pend = cur;
             cur = stack_next_of<!ANY || !CASTER_ANY_UNSORTED>(st, lane, tmax);

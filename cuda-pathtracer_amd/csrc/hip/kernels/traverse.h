@@ -262,24 +262,79 @@ constexpr int kTopF4 = 7;
 #ifndef CASTER_BRANCHY_NODE
 #define CASTER_BRANCHY_NODE 0   // 1: the exchange network and the pushes as branches (what the compiler makes of `if`)
 #endif
-template <bool SORT = true>
+// A ray's direction octant as the byte offsets, within a node record, of the three float4s that hold the planes
+// its direction reaches first: lo.x / hi.x at 0 / 48, lo.y / hi.y at 16 / 64, lo.z / hi.z at 32 / 80.  The planes
+// it reaches last lie at the offsets with these bits flipped.
+struct Octant { int nx, ny, nz; };
+constexpr int kOctFlipX = 48, kOctFlipY = 16 ^ 64, kOctFlipZ = 32 ^ 80;
+__device__ inline Octant octant_of(V3 inv) {
+  return Octant{inv.x < 0.f ? 48 : 0, inv.y < 0.f ? 64 : 16, inv.z < 0.f ? 80 : 32};
+}
+// Such a ray's slab test when 1 / direction is finite in every component: the nearer of an axis's two planes is
+// then known from the sign alone -- for lo <= hi, (lo - o) * inv <= (hi - o) * inv when inv > 0 and >= when inv < 0,
+// rounding included, since subtraction and multiplication by a finite number are monotone -- so the six minima and
+// maxima of box_test() fall away and the results are the same bit for bit.  (An empty child slot, lo = +inf and
+// hi = -inf, gives tNear = +inf and tFar = -inf here and fails without a look at its reference.)  With an
+// infinite component, (plane - o) * inv is not a number where the origin lies in the plane, box_test()'s minima
+// and maxima drop that operand, and which one they drop decides: such rays keep to box_test().
+__device__ inline bool box_test_octant(float nx, float ny, float nz, float fx, float fy, float fz, V3 o, V3 inv,
+                                       float tmax_slack, float scale, float& tn) {
+  float tNear = __builtin_fmaxf(__builtin_fmaxf((nx - o.x) * inv.x, (ny - o.y) * inv.y), (nz - o.z) * inv.z);
+  float tFar = __builtin_fminf(__builtin_fminf((fx - o.x) * inv.x, (fy - o.y) * inv.y), (fz - o.z) * inv.z);
+  tFar *= scale;
+  tn = tNear;
+  return !(tFar <= 0.00001f) && !(tNear > tFar) && !(tNear > tmax_slack);
+}
+__device__ inline float4 node_f4(const DevScene& S, uint32_t byte_offset) {
+  // (uniform base + 32-bit offset: one address instruction per load)
+  return *(const float4*)((const char*)S.nodes + byte_offset);
+}
+// OCT: the lane's ray has finite reciprocal direction and origin, `oct` is its octant (k_trace sees to both).
+template <bool SORT = true, bool OCT = false>
 __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float tmax, Stack& st, uint32_t lane,
-                                unsigned long long* overflow, const float4* top = nullptr, int n_top = 0) {
-  float4 lx, ly, lz, hx, hy, hz, rf;
-  if (cur < n_top) {
-    const float4* n = top + cur * kTopF4;
-    lx = lds_f4(n); ly = lds_f4(n + 1); lz = lds_f4(n + 2); hx = lds_f4(n + 3); hy = lds_f4(n + 4); hz = lds_f4(n + 5);
-    rf = lds_f4(n + 6);
-  } else {
-    const float4* n = S.nodes + (size_t)cur * kNodeF4;
-    lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; rf = n[6];
-  }
-  int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+                                unsigned long long* overflow, const float4* top = nullptr, int n_top = 0,
+                                Octant oct = Octant{0, 16, 32}) {
+  float4 rf;
   float k0, k1, k2, k3;
-  bool h0 = box_test(v3(lx.x, ly.x, lz.x), v3(hx.x, hy.x, hz.x), o, inv, tmax, S.box_scale, k0) && r0 != kRefEmpty;
-  bool h1 = box_test(v3(lx.y, ly.y, lz.y), v3(hx.y, hy.y, hz.y), o, inv, tmax, S.box_scale, k1) && r1 != kRefEmpty;
-  bool h2 = box_test(v3(lx.z, ly.z, lz.z), v3(hx.z, hy.z, hz.z), o, inv, tmax, S.box_scale, k2) && r2 != kRefEmpty;
-  bool h3 = box_test(v3(lx.w, ly.w, lz.w), v3(hx.w, hy.w, hz.w), o, inv, tmax, S.box_scale, k3) && r3 != kRefEmpty;
+  bool h0, h1, h2, h3;
+  int r0, r1, r2, r3;
+  if (OCT) {
+    float4 ax, ay, az, bx, by, bz;   // the planes reached first and last, of the four children
+    if (cur < n_top) {
+      const char* n = (const char*)top + cur * (kTopF4 * 16);
+      ax = lds_f4((const float4*)(n + oct.nx)); ay = lds_f4((const float4*)(n + oct.ny)); az = lds_f4((const float4*)(n + oct.nz));
+      bx = lds_f4((const float4*)(n + (oct.nx ^ kOctFlipX))); by = lds_f4((const float4*)(n + (oct.ny ^ kOctFlipY)));
+      bz = lds_f4((const float4*)(n + (oct.nz ^ kOctFlipZ)));
+      rf = lds_f4((const float4*)(n + 96));
+    } else {
+      const uint32_t b = (uint32_t)cur * (uint32_t)(kNodeF4 * 16);
+      ax = node_f4(S, b + (uint32_t)oct.nx); ay = node_f4(S, b + (uint32_t)oct.ny); az = node_f4(S, b + (uint32_t)oct.nz);
+      bx = node_f4(S, b + (uint32_t)(oct.nx ^ kOctFlipX)); by = node_f4(S, b + (uint32_t)(oct.ny ^ kOctFlipY));
+      bz = node_f4(S, b + (uint32_t)(oct.nz ^ kOctFlipZ));
+      rf = node_f4(S, b + 96u);
+    }
+    const float ts = tmax * fps::kNearCullSlack;
+    h0 = box_test_octant(ax.x, ay.x, az.x, bx.x, by.x, bz.x, o, inv, ts, S.box_scale, k0);
+    h1 = box_test_octant(ax.y, ay.y, az.y, bx.y, by.y, bz.y, o, inv, ts, S.box_scale, k1);
+    h2 = box_test_octant(ax.z, ay.z, az.z, bx.z, by.z, bz.z, o, inv, ts, S.box_scale, k2);
+    h3 = box_test_octant(ax.w, ay.w, az.w, bx.w, by.w, bz.w, o, inv, ts, S.box_scale, k3);
+    r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
+  } else {
+    float4 lx, ly, lz, hx, hy, hz;
+    if (cur < n_top) {
+      const float4* n = top + cur * kTopF4;
+      lx = lds_f4(n); ly = lds_f4(n + 1); lz = lds_f4(n + 2); hx = lds_f4(n + 3); hy = lds_f4(n + 4); hz = lds_f4(n + 5);
+      rf = lds_f4(n + 6);
+    } else {
+      const float4* n = S.nodes + (size_t)cur * kNodeF4;
+      lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; rf = n[6];
+    }
+    r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
+    h0 = box_test(v3(lx.x, ly.x, lz.x), v3(hx.x, hy.x, hz.x), o, inv, tmax, S.box_scale, k0) && r0 != kRefEmpty;
+    h1 = box_test(v3(lx.y, ly.y, lz.y), v3(hx.y, hy.y, hz.y), o, inv, tmax, S.box_scale, k1) && r1 != kRefEmpty;
+    h2 = box_test(v3(lx.z, ly.z, lz.z), v3(hx.z, hy.z, hz.z), o, inv, tmax, S.box_scale, k2) && r2 != kRefEmpty;
+    h3 = box_test(v3(lx.w, ly.w, lz.w), v3(hx.w, hy.w, hz.w), o, inv, tmax, S.box_scale, k3) && r3 != kRefEmpty;
+  }
   if (!(h0 || h1 || h2 || h3)) return stack_next_of<SORT>(st, lane, tmax);
   [[maybe_unused]] const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
 #if CASTER_BRANCHY_NODE

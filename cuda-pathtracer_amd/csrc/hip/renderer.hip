@@ -140,6 +140,10 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
           hi[0][k] = c.hi.x; hi[1][k] = c.hi.y; hi[2][k] = c.hi.z;
           if (c.leaf) ref[k] = leaf_ref(kids[k]);
           else { ref[k] = emit_node(); todo.push_back({kids[k], ref[k]}); }
+          // (a child without primitives gets the box of an empty slot: the octant slab test rejects a slot by
+          // its box alone)
+          if (ref[k] == kRefEmpty)
+            for (int a = 0; a < 3; ++a) { lo[a][k] = INFINITY; hi[a][k] = -INFINITY; }
         } else {
           for (int a = 0; a < 3; ++a) { lo[a][k] = INFINITY; hi[a][k] = -INFINITY; }
           ref[k] = kRefEmpty;
