@@ -102,6 +102,9 @@ __global__ void k_set_count(uint32_t* c, uint32_t v) { *c = v; }
 #ifndef CASTER_OCTANT_BOXES
 #define CASTER_OCTANT_BOXES 1   // 1: the node step reads a ray's near and far planes by its direction octant (box_test_octant)
 #endif
+#ifndef CASTER_OCTANT_GUARD
+#define CASTER_OCTANT_GUARD 1   // 0 (to see the test of axis-parallel rays fail): no ray keeps to the plain slab test
+#endif
 #ifndef CASTER_ANY_UNSORTED
 #define CASTER_ANY_UNSORTED 1
 #endif
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       r.inv = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
       r.maxD = maxabs3(r.d);
       r.oct = octant_of(r.inv);
-      r.plain = !(fabsf(r.inv.x) < INFINITY && fabsf(r.inv.y) < INFINITY && fabsf(r.inv.z) < INFINITY &&
+      r.plain = CASTER_OCTANT_GUARD && !(fabsf(r.inv.x) < INFINITY && fabsf(r.inv.y) < INFINITY && fabsf(r.inv.z) < INFINITY &&
                   fabsf(r.o.x) < INFINITY && fabsf(r.o.y) < INFINITY && fabsf(r.o.z) < INFINITY) ? 1 : 0;
       // every queued ray starts at the scene's epsilon; o.w carries a hit known
       // beforehand (a probe ray's nearest emitter, at distance tmax) or -1

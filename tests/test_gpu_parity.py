@@ -91,3 +91,50 @@ def test_traversal_kernel_against_oracle_ray_by_ray(caster, scenes):
             assert out[0] == t[i], (i, out[0], t[i])
     assert n // 3 < hits < n
     assert (prim[5::50] >= 0).sum() > 10                             # the unbounded-by-NaN rays hit things
+
+
+def test_traversal_kernel_rays_parallel_to_an_axis(caster, scenes):
+    """Rays with one or two direction components of exactly zero (1 / direction is then infinite), many of them
+    starting in a plane of a node's box, where (plane - origin) / 0 is not a number and the slab test's minima and
+    maxima decide by which operand they drop: the traversal kernel keeps such rays off its octant-addressed slab
+    test, and every hit equals the oracle's."""
+    import ctypes as C
+    sc = caster.Scene(scenes["stairs_pt"])
+    o = ol.Oracle(scenes["stairs_pt"])
+    boxes, meta, _ = sc.bvh()
+    rng = np.random.RandomState(21)
+    n = 4000
+    pick = boxes[rng.randint(0, len(boxes), n)]
+    org = (rng.rand(n, 3) * [6.0, 4.0, 6.0] + [-3.0, 0.2, -3.0]).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    axis = rng.randint(0, 3, n)
+    d[np.arange(n), axis] = 0.0                                      # parallel to the planes of that axis
+    two = rng.rand(n) < 0.3
+    d[two, (axis[two] + 1) % 3] = 0.0                                 # along a coordinate axis
+    d[rng.rand(n) < 0.25] *= -1.0
+    d[::5][d[::5] == 0.0] = -0.0                                      # both signs of zero
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(np.float32)
+    on_plane = rng.rand(n) < 0.7
+    side = rng.randint(0, 2, n)
+    rows = np.arange(n)[on_plane]
+    org[rows, axis[rows]] = pick[rows, axis[rows] + 3 * side[rows]]   # the origin lies in a lo or hi plane of some box
+    inside = rng.rand(n) < 0.5                                        # and for half of them within that box otherwise
+    for a in range(3):
+        m = on_plane & inside & (axis != a)
+        org[m, a] = (pick[m, a] + (pick[m, a + 3] - pick[m, a]) * rng.rand(m.sum())).astype(np.float32)
+    tmax = np.full(n, np.inf, np.float32)
+    tmax[1::4] = (rng.rand(len(tmax[1::4])) * 4).astype(np.float32)
+    r = caster.Renderer(sc, 0, 1)
+    prim, t = r.trace_rays(org, d, tmax)
+    r.close()
+    o.L.oracle_trace.restype = C.c_int
+    hits = 0
+    for i in range(n):
+        out = (C.c_float * 12)()
+        p = o.L.oracle_trace(o.h, (C.c_float * 3)(*org[i]), (C.c_float * 3)(*d[i]), C.c_float(sc.info.epsilon), C.c_float(tmax[i]), out)
+        assert p == prim[i], (i, p, prim[i], org[i], d[i])
+        if p >= 0:
+            hits += 1
+            assert out[0] == t[i], (i, out[0], t[i])
+    assert n // 4 < hits < n
