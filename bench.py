@@ -14,7 +14,7 @@ are summed onto rank 0 with one RCCL reduce inside the timed region.
 Started without a launcher, `--gpus N` starts its own N ranks (torch.distributed.run as a child process,
 before anything here touches a GPU) and passes rank 0's line on.
 
-Rank 0 prints one JSON line.  `roofline` prices the kernel with the largest share of the timed region with
+Rank 0 prints one JSON line.  `roofline` prices the kernel that takes most of the GPU's time with
 the bytes it itself requests (GPU-side counters: 112 B per 4-wide node record fetched + 48 B per primitive
 record tested + the ray and hit records moved) at the duration of a launch that has the GPU to itself,
 against the roof that applies (L2 bandwidth for the traversal's record gathers, HBM for the shade stage),
@@ -321,16 +321,24 @@ def main():
             o.render(1, 1, 1, counts=c1, rows=(y_mid, min(y_mid + 16, scene.height)))
             tc1 = time.perf_counter() - t0
             counts = c.as_dict()
-            cpu_model, sockets = "", set()
+            cpu_model, sockets, cpu_id = "", set(), {}
             try:
                 with open("/proc/cpuinfo") as f:
                     for l in f:
-                        if l.startswith("model name") and not cpu_model:
-                            cpu_model = l.split(":", 1)[1].strip()
-                        if l.startswith("physical id"):
-                            sockets.add(l.split(":", 1)[1].strip())
+                        key, _, val = l.partition(":")
+                        key, val = key.strip(), val.strip()
+                        if key == "model name" and not cpu_model:
+                            cpu_model = val
+                        if key in ("cpu family", "model", "stepping", "cpu MHz", "cache size") and key not in cpu_id:
+                            cpu_id[key] = val
+                        if key == "physical id":
+                            sockets.add(val)
             except OSError:
                 pass
+            if cpu_id:   # (a virtual machine may give no more than the vendor's family name as the model string)
+                cpu_model = "%s (family %s model %s stepping %s, %s MHz, cache %s)" % (
+                    cpu_model, cpu_id.get("cpu family", "?"), cpu_id.get("model", "?"), cpu_id.get("stepping", "?"),
+                    cpu_id.get("cpu MHz", "?"), cpu_id.get("cache size", "?"))
             out["cpu_baseline"] = {
                 "value": n_cpu / tc / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model,
                 "host_logical_cpus": os.cpu_count(), "cpus_this_process_may_use": host_cpus, "sockets": len(sockets) or None,
@@ -436,10 +444,10 @@ def main():
             st1, kt1, walk1 = r1.stats(), r1.kernel_times(), r1.walk_counts()
             r1.close()
             ex = [roofline_of(sym, kt1, st1["rays"], walk1, st1["samples"]) for sym in symbols]
-            dom_name = max(per_kernel, key=lambda k: k["total_ms"])["kernel"]
-            dom = next(k for k in ex if k["kernel"] == dom_name)
-            # the top level: the kernel with the largest share of the timed region, at the duration of a launch
-            # that has the GPU to itself
+            # the top level: the kernel that takes most of the GPU's time when every launch has the GPU to itself
+            # (in the timed region the streams' kernels share the CUs, and whose launches appear longest there
+            # changes from run to run)
+            dom = max(ex, key=lambda k: k["total_ms"])
             roof.update({k: v for k, v in dom.items()})
             roof["exclusive"] = {"streams": 1, "msamples_per_s": st1["samples"] / dt1 / 1e6, "kernels": ex,
                                  "requested_rate_gbs": sum(k["requested_bytes_per_launch"] * k["launches"] for k in ex) / dt1 / 1e9}
