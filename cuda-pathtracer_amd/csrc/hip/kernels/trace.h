@@ -132,14 +132,14 @@ struct WalkRay {
   int pend;  // a leaf waiting for its primitives to be tested (same encoding), kRefEmpty
   int sp;    // height of its stack
   int occluded;
-  Octant oct;  // direction octant (node_step<.., OCT>)
-  int plain;   // 1 / direction or the origin is not finite in some component: the ray keeps to the plain slab test
+  Octant oct;  // direction octant (node_step<.., OCT>); kOctPlain where 1 / direction or the origin is not finite in
+               // some component: the ray keeps to the plain slab test
 };
 __device__ inline void walk_ray_idle(WalkRay& r) {
   r.o = v3(0, 0, 0); r.d = v3(0, 0, 1); r.inv = v3(0, 0, 1); r.maxD = 1.f;
   r.hit.t = 0.f; r.hit.prim = -1; r.hit.b1 = r.hit.b2 = 0.f;
   r.idx = -1; r.cur = kRefEmpty; r.pend = kRefEmpty; r.sp = 0; r.occluded = 0;
-  r.oct = Octant{0, 16, 32}; r.plain = 0;
+  r.oct = Octant{0u, 0u};
 }
 __device__ inline float pick(bool second, float x0, float x1) { return second ? x1 : x0; }
 __device__ inline int pick(bool second, int x0, int x1) { return second ? x1 : x0; }
@@ -147,8 +147,14 @@ __device__ inline V3 pick(bool second, V3 x0, V3 x1) { return v3(pick(second, x0
 __device__ inline void put(bool second, float& x0, float& x1, float v) { x0 = second ? x0 : v; x1 = second ? v : x1; }
 __device__ inline void put(bool second, int& x0, int& x1, int v) { x0 = second ? x0 : v; x1 = second ? v : x1; }
 
+// (registers are budgeted for one wavefront per SIMD more than the grid brings: at 80 the kernel leaves room for
+// two wavefronts of a shade kernel beside four of its own, at 96 for one -- which is what the small scenes, where
+// the streams' kernels really run side by side, notice)
+#ifndef CASTER_TRACE_REG_WAVES
+#define CASTER_TRACE_REG_WAVES (CASTER_TRACE_WAVES + 1)
+#endif
 template <bool ANY>
-__global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
+__global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
   __shared__ uint2 s_stack[kTraceBlockWaves][kTraceRays * kLdsDepth][kWave];
   __shared__ float4 s_top[kTopNodes > 0 ? kTopNodes * kTopF4 : 1];
 #ifdef CASTER_WALK_STATS
@@ -258,9 +264,9 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
       r.o = v3(o4); r.d = v3(d4);
       r.inv = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
       r.maxD = maxabs3(r.d);
-      r.oct = octant_of(r.inv);
-      r.plain = CASTER_OCTANT_GUARD && !(fabsf(r.inv.x) < INFINITY && fabsf(r.inv.y) < INFINITY && fabsf(r.inv.z) < INFINITY &&
-                  fabsf(r.o.x) < INFINITY && fabsf(r.o.y) < INFINITY && fabsf(r.o.z) < INFINITY) ? 1 : 0;
+      r.oct = octant_of(r.inv, CASTER_OCTANT_GUARD &&
+                               !(fabsf(r.inv.x) < INFINITY && fabsf(r.inv.y) < INFINITY && fabsf(r.inv.z) < INFINITY &&
+                                 fabsf(r.o.x) < INFINITY && fabsf(r.o.y) < INFINITY && fabsf(r.o.z) < INFINITY));
       // every queued ray starts at the scene's epsilon; o.w carries a hit known
       // beforehand (a probe ray's nearest emitter, at distance tmax) or -1
       r.hit.t = d4.w; r.hit.prim = __float_as_int(o4.w); r.hit.b1 = r.hit.b2 = 0.f;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
         int cur = pick(w, a.cur, b.cur);
         n_node_fetches += (uint32_t)__popcll(lane_ballot(cur >= n_top));
         // (one ray in 10^7 is parallel to an axis; the whole step then takes the plain slab test)
-        const bool plain_step = !CASTER_OCTANT_BOXES || any_lane(cur >= 0 && (kTraceRays == 2 ? (a.plain | b.plain) : a.plain) != 0);
+        const bool plain_step = !CASTER_OCTANT_BOXES || any_lane(cur >= 0 && ((kTraceRays == 2 ? (a.oct.b | b.oct.b) : a.oct.b) & kOctPlain) != 0);
         if (cur >= 0) {
           const V3 o = pick(w, a.o, b.o), inv = pick(w, a.inv, b.inv);
           const float tmax = pick(w, a.hit.t, b.hit.t);
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_WAVES) void 
         n_prim_tests += (uint32_t)n_leaf;   // (every lane that holds a leaf tests one primitive)
         if (pend != kRefEmpty) {
           const V3 o = pick(w, a.o, b.o), d = pick(w, a.d, b.d), inv = pick(w, a.inv, b.inv);
-          const float maxD = pick(w, a.maxD, b.maxD);
+          const float maxD = kTraceRays == 2 ? pick(w, a.maxD, b.maxD) : maxabs3(d);   // (one v_max3 against a register held)
           float ht = pick(w, a.hit.t, b.hit.t);
           const int hp = pick(w, a.hit.prim, b.hit.prim);
           int cur = pick(w, a.cur, b.cur);

@@ -262,13 +262,28 @@ constexpr int kTopF4 = 7;
 #ifndef CASTER_BRANCHY_NODE
 #define CASTER_BRANCHY_NODE 0   // 1: the exchange network and the pushes as branches (what the compiler makes of `if`)
 #endif
-// A ray's direction octant as the byte offsets, within a node record, of the three float4s that hold the planes
-// its direction reaches first: lo.x / hi.x at 0 / 48, lo.y / hi.y at 16 / 64, lo.z / hi.z at 32 / 80.  The planes
-// it reaches last lie at the offsets with these bits flipped.
-struct Octant { int nx, ny, nz; };
-constexpr int kOctFlipX = 48, kOctFlipY = 16 ^ 64, kOctFlipZ = 32 ^ 80;
-__device__ inline Octant octant_of(V3 inv) {
-  return Octant{inv.x < 0.f ? 48 : 0, inv.y < 0.f ? 64 : 16, inv.z < 0.f ? 80 : 32};
+// A ray's direction octant as byte offsets into a node record: of the three float4s that hold the planes its
+// direction reaches first (lo.x / hi.x at 0 / 48, lo.y / hi.y at 16 / 64, lo.z / hi.z at 32 / 80) and of the three it
+// reaches last, a byte each, packed into two registers.  The traversal kernel adds them to a node's offset with
+// byte-selecting adds (one instruction per load address, no unpacking).
+struct Octant {
+  uint32_t a;   // near x | near y << 8 | near z << 16 | far x << 24
+  uint32_t b;   // far y | far z << 8 | kOctPlain when the ray keeps to the plain slab test
+};
+constexpr uint32_t kOctPlain = 1u << 16;
+__device__ inline Octant octant_of(V3 inv, bool plain) {
+  const uint32_t nx = inv.x < 0.f ? 48u : 0u, ny = inv.y < 0.f ? 64u : 16u, nz = inv.z < 0.f ? 80u : 32u;
+  return Octant{nx | (ny << 8) | (nz << 16) | ((48u - nx) << 24), (80u - ny) | ((112u - nz) << 8) | (plain ? kOctPlain : 0u)};
+}
+// base + byte K of `packed`
+template <int K>
+__device__ inline uint32_t add_byte(uint32_t base, uint32_t packed) {
+  uint32_t r;
+  if (K == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(base), "v"(packed));
+  if (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(base), "v"(packed));
+  if (K == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(base), "v"(packed));
+  if (K == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(packed));
+  return r;
 }
 // Such a ray's slab test when 1 / direction is finite in every component: the nearer of an axis's two planes is
 // then known from the sign alone -- for lo <= hi, (lo - o) * inv <= (hi - o) * inv when inv > 0 and >= when inv < 0,
@@ -293,7 +308,7 @@ __device__ inline float4 node_f4(const DevScene& S, uint32_t byte_offset) {
 template <bool SORT = true, bool OCT = false>
 __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float tmax, Stack& st, uint32_t lane,
                                 unsigned long long* overflow, const float4* top = nullptr, int n_top = 0,
-                                Octant oct = Octant{0, 16, 32}) {
+                                Octant oct = Octant{0u, 0u}) {
   float4 rf;
   float k0, k1, k2, k3;
   bool h0, h1, h2, h3;
@@ -301,16 +316,16 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
   if (OCT) {
     float4 ax, ay, az, bx, by, bz;   // the planes reached first and last, of the four children
     if (cur < n_top) {
-      const char* n = (const char*)top + cur * (kTopF4 * 16);
-      ax = lds_f4((const float4*)(n + oct.nx)); ay = lds_f4((const float4*)(n + oct.ny)); az = lds_f4((const float4*)(n + oct.nz));
-      bx = lds_f4((const float4*)(n + (oct.nx ^ kOctFlipX))); by = lds_f4((const float4*)(n + (oct.ny ^ kOctFlipY)));
-      bz = lds_f4((const float4*)(n + (oct.nz ^ kOctFlipZ)));
-      rf = lds_f4((const float4*)(n + 96));
+      const uint32_t b = (uint32_t)(size_t)top + (uint32_t)cur * (uint32_t)(kTopF4 * 16);   // (an LDS address is 32 bits)
+      typedef __attribute__((address_space(3))) const float4 lds_cf4;
+      auto at = [](uint32_t a) { return lds_f4((const float4*)(lds_cf4*)(size_t)a); };
+      ax = at(add_byte<0>(b, oct.a)); ay = at(add_byte<1>(b, oct.a)); az = at(add_byte<2>(b, oct.a));
+      bx = at(add_byte<3>(b, oct.a)); by = at(add_byte<0>(b, oct.b)); bz = at(add_byte<1>(b, oct.b));
+      rf = at(b + 96u);
     } else {
       const uint32_t b = (uint32_t)cur * (uint32_t)(kNodeF4 * 16);
-      ax = node_f4(S, b + (uint32_t)oct.nx); ay = node_f4(S, b + (uint32_t)oct.ny); az = node_f4(S, b + (uint32_t)oct.nz);
-      bx = node_f4(S, b + (uint32_t)(oct.nx ^ kOctFlipX)); by = node_f4(S, b + (uint32_t)(oct.ny ^ kOctFlipY));
-      bz = node_f4(S, b + (uint32_t)(oct.nz ^ kOctFlipZ));
+      ax = node_f4(S, add_byte<0>(b, oct.a)); ay = node_f4(S, add_byte<1>(b, oct.a)); az = node_f4(S, add_byte<2>(b, oct.a));
+      bx = node_f4(S, add_byte<3>(b, oct.a)); by = node_f4(S, add_byte<0>(b, oct.b)); bz = node_f4(S, add_byte<1>(b, oct.b));
       rf = node_f4(S, b + 96u);
     }
     const float ts = tmax * fps::kNearCullSlack;
