@@ -481,6 +481,9 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   if ((rc = dev_upload(r, &S.tex_info, A.tex_info))) return rc;
   if ((rc = dev_upload(r, &S.inf.data, A.env))) return rc;
   S.n_prims = (int)sc.prims.size();
+  // (the traversal kernel addresses node records with 32-bit byte offsets from the array's start)
+  if (A.nodes.size() * sizeof(float4) > (size_t)UINT32_MAX)
+    return fail(CASTER_ERR_ARG, "caster_begin: the tree's node array exceeds 4 GiB (" + std::to_string(A.nodes.size() / kNodeF4) + " wide nodes)");
   S.n_nodes = (int)(A.nodes.size() / kNodeF4);
   S.n_lights = (int)sc.lights.size();
   S.n_cdf = (int)sc.light_cdf.size();
