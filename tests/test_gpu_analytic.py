@@ -1,0 +1,39 @@
+"""The HIP renderer, through the C-ABI, against answers that come from neither the reference's text nor the CPU
+oracle: the form-factor integral of a rectangular emitter over a Lambertian floor, and the closed-form radiance of a
+convex body inside a uniform environment (scenes and formulas: test_oracle_independent.py).  The other GPU tests
+compare with the oracle; these hold the product itself against textbook radiometry."""
+import numpy as np
+import pytest
+
+import test_oracle_independent as ind
+
+pytestmark = pytest.mark.gpu
+
+
+def render_mean(caster, path, spp):
+    sc = caster.Scene(path)
+    r = caster.Renderer(sc, 0, 8)
+    r.render(1, spp, True)
+    img = r.read_film(0)          # linear mean, row 0 = bottom scanline
+    st = r.stats()
+    r.close()
+    assert st["stack_overflow"] == 0 and st["invalid"] == 0
+    return img
+
+
+def test_direct_light_of_a_rectangle_matches_the_form_factor(caster, tmp_path):
+    path, patch, want = ind.form_factor_scene(str(tmp_path))
+    img = render_mean(caster, path, 1024)
+    got = float(img[patch].mean())
+    print("floor radiance", got, "form factor", want)
+    assert abs(got - want) <= 0.005 * want, (got, want)
+
+
+@pytest.mark.parametrize("bsdf,want", ind.FURNACE)
+def test_a_convex_body_in_a_uniform_environment_shows_its_albedo(caster, tmp_path, bsdf, want):
+    path, body, corner = ind.furnace_scene(str(tmp_path), bsdf)
+    img = render_mean(caster, path, 512)
+    assert abs(float(img[corner].mean()) - 1.0) < 1e-5
+    got = float(img[body].mean())
+    print(bsdf, "sphere in the furnace", got, "expected", want)
+    assert abs(got - want) <= 0.005 * want, (bsdf, got, want)

@@ -1,0 +1,290 @@
+"""Checks of the CPU oracle against answers that do NOT come from transcribing the reference.
+
+The oracle and the HIP kernels are written from the same text, so their agreeing bit for bit cannot show a
+misreading made on both sides.  These tests hold the oracle (and through the parity tests the kernels) against
+geometry and radiometry worked out independently, in float64 and from textbook formulas:
+
+* closest hits of random rays against an exhaustive float64 search over the scene's triangles and spheres
+  (plane intersection + edge functions; the sphere's quadratic), which is not the reference's formulation
+  (Triangle.h:87-118 is Moeller-Trumbore with an error bound, sphere.h:24-66 orders its roots by hand);
+* area-light samples (area.h:12-17): the point lies on the emitter, the density is the solid-angle density of a
+  uniform point on it, and the mean of 1/pdf over a stratified grid is the triangle's solid angle (Van Oosterom &
+  Strackee) -- which only a uniform distribution over the triangle gives;
+* camera rays (Camera.h:45-85): the field of view, the image's orientation, the viewing direction;
+* whole integrals through Path() (pathtracer.cu:873-1011): a Lambertian floor under a one-sided rectangular emitter
+  against the form-factor integral, and a convex Lambertian / mirror / glass sphere inside a uniform environment
+  ("furnace"), whose radiance is known in closed form whatever the sampling strategy.
+
+They run on the CPU in seconds.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+
+def write_obj(path, tris, normals):
+    """Triangles (n, 3, 3) with one normal each, as an OBJ with `vn` (what the loader wants)."""
+    with open(path, "w") as f:
+        for t in tris:
+            for v in t:
+                f.write("v %.9g %.9g %.9g\n" % tuple(v))
+        for n in normals:
+            f.write("vn %.9g %.9g %.9g\n" % tuple(n))
+        for i in range(len(tris)):
+            a = 3 * i + 1
+            f.write("f %d//%d %d//%d %d//%d\n" % (a, i + 1, a + 1, i + 1, a + 2, i + 1))
+
+
+def write_scene(d, doc):
+    path = os.path.join(d, "scene.json")
+    with open(path, "w") as f:
+        json.dump(doc, f)
+    return path
+
+
+def write_constant_pfm(path, value, w=8, h=4):
+    img = np.full((h, w, 3), value, "<f4")
+    with open(path, "wb") as f:
+        f.write(b"PF\n%d %d\n-1.0\n" % (w, h))
+        f.write(img.tobytes())
+
+
+def face_normals(tris):
+    n = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+    return n / np.linalg.norm(n, axis=1, keepdims=True)
+
+
+# ------------------------------------------------------------------ closest hits
+def closest_hit_f64(o, d, tris, spheres, tmin, tmax):
+    """Exhaustive search in float64: (index into tris + spheres, distance) or (-1, inf)."""
+    best, best_t = -1, np.inf
+    n = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+    denom = n @ d
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.einsum("ij,ij->i", n, tris[:, 0] - o) / denom
+    p = o + t[:, None] * d
+    inside = np.ones(len(tris), bool)
+    for k in range(3):   # edge functions: p on the inner side of every edge
+        e = tris[:, (k + 1) % 3] - tris[:, k]
+        inside &= np.einsum("ij,ij->i", np.cross(e, p - tris[:, k]), n) >= 0
+    ok = inside & np.isfinite(t) & (t >= tmin) & (t <= tmax)
+    if ok.any():
+        i = int(np.argmin(np.where(ok, t, np.inf)))
+        best, best_t = i, float(t[i])
+    for j, (c, r) in enumerate(spheres):
+        oc = o - c
+        b = oc @ d
+        disc = b * b - (oc @ oc - r * r)
+        if disc < 0:
+            continue
+        s = np.sqrt(disc)
+        for root in (-b - s, -b + s):
+            if root > tmin and root <= tmax:
+                if root < best_t:
+                    best, best_t = len(tris) + j, float(root)
+                break
+    return best, best_t
+
+
+def test_closest_hits_against_an_exhaustive_float64_search(caster, tmp_path):
+    rng = np.random.RandomState(5)
+    n_tri = 60
+    centre = rng.rand(n_tri, 1, 3) * 2 - 1
+    tris = centre + (rng.rand(n_tri, 3, 3) - 0.5) * 1.6
+    spheres = [(np.array([0.3, -0.2, 0.1]), 0.35), (np.array([-0.5, 0.4, -0.3]), 0.25), (np.array([0.0, 0.7, 0.6]), 0.2)]
+    d = str(tmp_path)
+    write_obj(os.path.join(d, "soup.obj"), tris, face_normals(tris))
+    doc = {"screen_width": 32, "screen_height": 32, "epsilon": 0.001, "integrator": "pt", "maxDepth": 2,
+           "camera": {"position": [0, 0, 5], "lookat": [0, 0, 0], "up": [0, 1, 0], "fov": 40},
+           "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [0.5, 0.5, 0.5]}],
+           "scene": [{"mesh": "soup.obj", "material": "m"}] +
+                    [{"sphere": True, "center": [float(x) for x in c], "radius": r, "material": "m"} for c, r in spheres],
+           "light": []}
+    path = write_scene(d, doc)
+    o = ol.Oracle(path)
+    _, _, push = caster.Scene(path).bvh()          # canonical (tree) order -> push order: mesh faces first, then the spheres
+    # float32 data as the loader holds them
+    tris32 = tris.astype(np.float32).astype(np.float64)
+    sph32 = [(c.astype(np.float32).astype(np.float64), float(np.float32(r))) for c, r in spheres]
+    n_rays, wrong, hits = 3000, 0, 0
+    for i in range(n_rays):
+        org = (rng.rand(3) * 2.4 - 1.2).astype(np.float32)
+        dr = rng.normal(size=3)
+        dr = (dr / np.linalg.norm(dr)).astype(np.float32)
+        tmax = np.inf if i % 3 else float(np.float32(rng.rand() * 2.5))
+        prim, rec = o.trace(org, dr, 1e-3, tmax)
+        want, want_t = closest_hit_f64(org.astype(np.float64), dr.astype(np.float64), tris32, sph32, 1e-3, tmax)
+        got = int(push[prim]) if prim >= 0 else -1
+        if got != want or (got >= 0 and abs(rec[0] - want_t) > 2e-4 * (1 + want_t)):
+            wrong += 1                                # (a ray through an edge or grazing a silhouette may fall either way)
+        hits += got >= 0
+    print("hits", hits, "disagreements", wrong)
+    assert hits > n_rays // 3
+    assert wrong <= n_rays * 0.004, "%d of %d rays disagree with the float64 search" % (wrong, n_rays)
+
+
+# ------------------------------------------------------------------ area light
+def triangle_solid_angle(p, a, b, c):
+    """Van Oosterom & Strackee (1983)."""
+    ra, rb, rc = a - p, b - p, c - p
+    la, lb, lc = np.linalg.norm(ra), np.linalg.norm(rb), np.linalg.norm(rc)
+    num = ra @ np.cross(rb, rc)
+    den = la * lb * lc + (ra @ rb) * lc + (ra @ rc) * lb + (rb @ rc) * la
+    return abs(2 * np.arctan2(num, den))
+
+
+def test_area_light_samples_are_uniform_on_the_emitter_with_the_solid_angle_density(tmp_path):
+    d = str(tmp_path)
+    quad = np.array([[[-0.4, 2.0, -0.3], [0.5, 2.0, -0.3], [0.5, 2.0, 0.45]],
+                     [[-0.4, 2.0, -0.3], [0.5, 2.0, 0.45], [-0.4, 2.0, 0.45]]])
+    down = np.array([[0, -1, 0], [0, -1, 0]], float)
+    write_obj(os.path.join(d, "light.obj"), quad, down)
+    floor = np.array([[[-3, 0, 3], [3, 0, 3], [3, 0, -3]], [[-3, 0, 3], [3, 0, -3], [-3, 0, -3]]], float)
+    write_obj(os.path.join(d, "floor.obj"), floor, np.array([[0, 1, 0], [0, 1, 0]], float))
+    doc = {"screen_width": 16, "screen_height": 16, "integrator": "pt", "maxDepth": 1,
+           "camera": {"position": [0, 1, 5], "lookat": [0, 0, 0], "up": [0, 1, 0], "fov": 30},
+           "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [0.5, 0.5, 0.5]}],
+           "scene": [{"mesh": "floor.obj", "material": "m"}],
+           "light": [{"mesh": "light.obj", "material": "m", "radiance": [3, 2, 1]}]}
+    o = ol.Oracle(write_scene(d, doc))
+    pos = np.array([0.3, 0.2, -0.1])
+    n_side = 48
+    for light in (0, 1):
+        tri = quad[light].astype(np.float32).astype(np.float64)
+        area = 0.5 * np.linalg.norm(np.cross(tri[1] - tri[0], tri[2] - tri[0]))
+        inv_pdf = []
+        for i in range(n_side):
+            for j in range(n_side):
+                s = o.light_sample(light, pos, [(i + 0.5) / n_side, (j + 0.5) / n_side])
+                rad, dr, tmax, nor, pdf = s[0:3], s[3:6].astype(np.float64), float(s[6]), s[7:10], float(s[10])
+                assert tuple(rad) == (3.0, 2.0, 1.0)
+                # the sampled point: on the emitter's plane and inside the triangle
+                t_plane = (2.0 - pos[1]) / dr[1]
+                p = pos + t_plane * dr
+                assert abs(t_plane - tmax) < 2e-3                    # (the reference shortens the shadow ray: sqrt(d^2 - eps))
+                nrm = np.cross(tri[1] - tri[0], tri[2] - tri[0])
+                for k in range(3):
+                    e = tri[(k + 1) % 3] - tri[k]
+                    assert np.cross(e, p - tri[k]) @ nrm >= -1e-5
+                # the density of a uniform point on the triangle, per solid angle
+                want = t_plane * t_plane / (area * abs(dr[1]))
+                assert abs(pdf - want) <= 2e-4 * want
+                inv_pdf.append(1.0 / pdf)
+        omega = triangle_solid_angle(pos, *tri)
+        assert abs(np.mean(inv_pdf) - omega) <= 0.01 * omega
+    # one-sided: seen from above, the emitter is black
+    s = o.light_sample(0, np.array([0.0, 3.0, 0.0]), [0.3, 0.6])
+    assert tuple(s[0:3]) == (0.0, 0.0, 0.0)
+
+
+# ------------------------------------------------------------------ camera
+def test_camera_rays_span_the_field_of_view_about_the_viewing_direction(tmp_path):
+    d = str(tmp_path)
+    floor = np.array([[[-3, 0, 3], [3, 0, 3], [3, 0, -3]]], float)
+    write_obj(os.path.join(d, "floor.obj"), floor, np.array([[0, 1, 0]], float))
+    w, h, fov = 200, 100, 35.0
+    eye, look = np.array([1.0, 2.0, 5.0]), np.array([0.5, 0.0, -1.0])
+    doc = {"screen_width": w, "screen_height": h, "integrator": "pt", "maxDepth": 1,
+           "camera": {"position": list(eye), "lookat": list(look), "up": [0, 1, 0], "fov": fov},
+           "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [0.5, 0.5, 0.5]}],
+           "scene": [{"mesh": "floor.obj", "material": "m"}], "light": []}
+    o = ol.Oracle(write_scene(d, doc))
+    view = (look - eye) / np.linalg.norm(look - eye)
+    px_angle = np.radians(fov) / h                      # one pixel, roughly (rays are jittered within their pixel)
+
+    def ray(x, y):
+        r = o.camera_ray(x, y, 1)
+        assert np.allclose(r[0:3], eye, atol=1e-6)
+        dr = r[3:6].astype(np.float64)
+        assert abs(np.linalg.norm(dr) - 1) < 1e-5
+        return dr
+
+    centre = ray(w // 2, h // 2)
+    assert np.arccos(np.clip(centre @ view, -1, 1)) < 1.5 * px_angle
+    top, bottom = ray(w // 2, h - 1), ray(w // 2, 0)
+    assert top[1] > bottom[1]                           # row 0 is the bottom scanline (Camera.h:58)
+    assert abs(np.arccos(np.clip(top @ bottom, -1, 1)) - np.radians(fov)) < 2.5 * px_angle   # fov is the vertical angle
+    left, right = ray(0, h // 2), ray(w - 1, h // 2)
+    horizontal = 2 * np.arctan(np.tan(np.radians(fov) / 2) * w / h)
+    assert abs(np.arccos(np.clip(left @ right, -1, 1)) - horizontal) < 2.5 * px_angle
+    side = np.cross(view, [0, 1, 0])
+    assert right @ side > 0 > left @ side               # x grows to the viewer's right
+
+
+# ------------------------------------------------------------------ integrals through Path()
+def form_factor_scene(d):
+    """A Lambertian floor under a one-sided rectangular emitter, seen from the side through a narrow lens: the scene
+    file, the pixels that show the floor about the origin, and their radiance by the form-factor integral."""
+    x0, x1, z0, z1, hgt = -0.6, 0.4, -0.5, 0.7, 1.5
+    quad = np.array([[[x0, hgt, z0], [x1, hgt, z0], [x1, hgt, z1]], [[x0, hgt, z0], [x1, hgt, z1], [x0, hgt, z1]]])
+    write_obj(os.path.join(d, "light.obj"), quad, np.array([[0, -1, 0], [0, -1, 0]], float))
+    floor = np.array([[[-50, 0, 50], [50, 0, 50], [50, 0, -50]], [[-50, 0, 50], [50, 0, -50], [-50, 0, -50]]], float)
+    write_obj(os.path.join(d, "floor.obj"), floor, np.array([[0, 1, 0], [0, 1, 0]], float))
+    rho, L = 0.6, 5.0
+    w = h = 24
+    doc = {"screen_width": w, "screen_height": h, "integrator": "pt", "maxDepth": 1,
+           "camera": {"position": [4.0, 1.0, 0.0], "lookat": [0, 0, 0], "up": [0, 1, 0], "fov": 1.5, "filmicTonemap": False},
+           "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [rho, rho, rho]}],
+           "scene": [{"mesh": "floor.obj", "material": "m"}],
+           "light": [{"mesh": "light.obj", "material": "m", "radiance": [L, L, L]}]}
+    # irradiance at the origin from the rectangle: integral of cos_p cos_l / r^2 dA, by quadrature
+    n = 400
+    xs = x0 + (np.arange(n) + 0.5) * (x1 - x0) / n
+    zs = z0 + (np.arange(n) + 0.5) * (z1 - z0) / n
+    X, Z = np.meshgrid(xs, zs)
+    r2 = X * X + Z * Z + hgt * hgt
+    E = L * np.sum(hgt * hgt / (r2 * r2)) * (x1 - x0) * (z1 - z0) / (n * n)
+    patch = (slice(h // 2 - 2, h // 2 + 2), slice(w // 2 - 2, w // 2 + 2))
+    return write_scene(d, doc), patch, rho / np.pi * E
+
+
+def test_direct_light_of_a_rectangle_on_a_lambertian_floor_matches_the_form_factor(tmp_path):
+    path, patch, want = form_factor_scene(str(tmp_path))
+    o = ol.Oracle(path)
+    spp = 256
+    img = o.render(1, spp, 8) / spp
+    got = float(img[patch].mean())
+    print("floor radiance", got, "form factor", want)
+    assert abs(got - want) <= 0.01 * want, (got, want)
+
+
+FURNACE = [("lambertian", 0.5), ("mirror", 1.0), ("dielectric", 1.0)]
+
+
+def furnace_scene(d, bsdf):
+    """A unit sphere of the given material inside an environment of radiance 1: the scene file, the pixels at the
+    middle of the sphere, a corner of the image (the environment itself)."""
+    write_constant_pfm(os.path.join(d, "env.pfm"), 1.0)
+    mat = {"name": "m", "bsdf": bsdf, "diffuse": [0.5, 0.5, 0.5]}
+    if bsdf == "dielectric":
+        mat.update({"insideIOR": 1.5, "outsideIOR": 1.0})
+    w = h = 32
+    doc = {"screen_width": w, "screen_height": h, "integrator": "pt", "maxDepth": 24,
+           "camera": {"position": [0, 0, 4], "lookat": [0, 0, 0], "up": [0, 1, 0], "fov": 30, "filmicTonemap": False},
+           "material": [mat],
+           "scene": [{"sphere": True, "center": [0, 0, 0], "radius": 1.0, "material": "m"}],
+           "light": [{"infinite": "env.pfm"}]}
+    body = (slice(h // 2 - 5, h // 2 + 5), slice(w // 2 - 5, w // 2 + 5))
+    corner = (slice(0, 3), slice(0, 3))
+    return write_scene(d, doc), body, corner
+
+
+@pytest.mark.parametrize("bsdf,want", FURNACE)
+def test_a_convex_body_in_a_uniform_environment_shows_its_albedo(tmp_path, bsdf, want):
+    """Furnace: under an environment of radiance 1 from every direction a convex Lambertian body of albedo rho has
+    radiance rho wherever it is seen (every reflected ray leaves for the environment), a mirror and a clear
+    dielectric show 1 (Fresnel reflection and refraction add up, and the radiance scaling of a refraction going in
+    is undone going out).  Light sampling, BSDF sampling and their MIS weights must add up to exactly that."""
+    path, body, corner = furnace_scene(str(tmp_path), bsdf)
+    o = ol.Oracle(path)
+    spp = 96
+    img = o.render(1, spp, 8) / spp
+    assert abs(float(img[corner].mean()) - 1.0) < 1e-5            # the environment itself
+    got = float(img[body].mean())
+    print(bsdf, "sphere in the furnace", got, "expected", want)
+    # (Russian roulette keeps the estimate unbiased; what is cut off at maxDepth 24 inside the glass is < 1e-6)
+    assert abs(got - want) <= 0.01 * want, (bsdf, got, want)
