@@ -37,3 +37,37 @@ def test_a_convex_body_in_a_uniform_environment_shows_its_albedo(caster, tmp_pat
     got = float(img[body].mean())
     print(bsdf, "sphere in the furnace", got, "expected", want)
     assert abs(got - want) <= 0.005 * want, (bsdf, got, want)
+
+
+@pytest.mark.parametrize("boundary", ["matched", "glass"])
+def test_a_scattering_medium_without_absorption_in_a_uniform_environment_shows_one(caster, tmp_path, boundary):
+    path, body = ind.volume_furnace_scene(str(tmp_path), boundary)
+    sc = caster.Scene(path)
+    r = caster.Renderer(sc, 0, 8)
+    r.render(1, 1024, True)
+    img = r.read_film(0)
+    st = r.stats()
+    r.close()
+    assert st["stack_overflow"] == 0
+    got = img[body].reshape(-1, 3).mean(axis=0)
+    print(boundary, "cube of fog in the furnace", got, "invalid samples", st["invalid"])
+    assert np.all(np.abs(got - 1.0) <= 0.03), got
+
+
+def test_an_emitter_seen_through_an_absorbing_medium_is_attenuated_twice_as_in_the_reference(caster, tmp_path):
+    """(pathtracer.cu:1093-1101 applies the transmittance on top of a throughput that already carries it: see the
+    oracle's test of the same name.)"""
+    path, patch, want = ind.absorption_scene(str(tmp_path))
+    img = render_mean(caster, path, 1024)
+    got = img[patch].reshape(-1, 3).mean(axis=0)
+    twice = want * want / 3.0
+    print("through the medium", got, "attenuated twice", twice)
+    assert np.all(np.abs(got - twice) <= 0.02 * twice), (got, twice)
+
+
+@pytest.mark.parametrize("wall,want", [(False, np.pi), (True, np.pi / 2)])
+def test_ambient_occlusion_of_an_open_floor_and_at_the_foot_of_a_wall(caster, tmp_path, wall, want):
+    img = render_mean(caster, ind.ao_scene(str(tmp_path), wall), 1024)
+    got = float(img.mean())
+    print("AO", "at the foot of a wall" if wall else "open floor", got, "expected", want)
+    assert abs(got - want) <= (0.01 if wall else 1e-4) * want
