@@ -1393,6 +1393,8 @@ bool Volpath(const Ctx& cx, uint32_t pixel, uint32_t iter, V3& color, Counters& 
       if (bounces == 0 || specular) {
         if (isect.lightIdx != -1) {
           V3 tr = v3(1.f, 1.f, 1.f);
+          // (as the reference has it: beta already carries the transmittance of the medium sample that reached
+          // this surface, so an emitter seen through a medium is attenuated twice -- tests/test_oracle_independent.py)
           if (r.medium != -1) tr = MediumTr(cx.scene.media[r.medium], r, rng);
           Li += tr * beta * AreaLe(cx, isect.lightIdx, nor, -r.dir);
           break;
