@@ -409,3 +409,34 @@ def test_ambient_occlusion_of_an_open_floor_and_at_the_foot_of_a_wall(tmp_path, 
     got = float(img.mean())
     print("AO", "at the foot of a wall" if wall else "open floor", got, "expected", want)
     assert abs(got - want) <= (0.02 if wall else 1e-4) * want     # (a direction in the horizon may round below it)
+
+
+# ------------------------------------------------------------------ thin lens
+def test_thin_lens_rays_of_one_pixel_meet_on_the_plane_of_focus(tmp_path):
+    """With an aperture, the rays of one pixel start all over the lens and cross where the pinhole ray of that image
+    point meets the plane at the focal distance (a thin lens focused there): up to the jitter inside the pixel."""
+    d = str(tmp_path)
+    floor = np.array([[[-3, 0, 3], [3, 0, 3], [3, 0, -3]]], float)
+    write_obj(os.path.join(d, "floor.obj"), floor, np.array([[0, 1, 0]], float))
+    w, h, fov, focal, radius = 64, 48, 30.0, 3.5, 0.2
+    eye, look = np.array([0.5, 1.0, 4.0]), np.array([0.0, 0.5, 0.0])
+    doc = {"screen_width": w, "screen_height": h, "integrator": "pt", "maxDepth": 1,
+           "camera": {"position": list(eye), "lookat": list(look), "up": [0, 1, 0], "fov": fov, "apertureRadius": radius, "focalDistance": focal},
+           "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [0.5, 0.5, 0.5]}],
+           "scene": [{"mesh": "floor.obj", "material": "m"}], "light": []}
+    o = ol.Oracle(write_scene(d, doc))
+    view = (look - eye) / np.linalg.norm(look - eye)
+    pixel = 2 * focal * np.tan(np.radians(fov) / 2) / h          # a pixel's footprint on the plane of focus
+    for x, y in ((10, 7), (32, 24), (60, 40)):
+        starts, crossings = [], []
+        for it in range(1, 41):
+            r = o.camera_ray(x, y, it)
+            org, dr = r[0:3].astype(np.float64), r[3:6].astype(np.float64)
+            t = focal / (dr @ view)                              # where the ray meets the plane view . (p - eye) = focal
+            starts.append(org - eye)
+            crossings.append(org + t * dr)
+        starts, crossings = np.array(starts), np.array(crossings)
+        assert np.abs(starts @ view).max() < 1e-5                # origins lie in the lens plane
+        spread = np.linalg.norm(starts, axis=1)
+        assert spread.max() <= radius * 1.0001 and spread.max() > 0.6 * radius    # ... all over the aperture disk
+        assert np.linalg.norm(crossings - crossings.mean(axis=0), axis=1).max() <= 1.05 * pixel
