@@ -71,3 +71,23 @@ def test_ambient_occlusion_of_an_open_floor_and_at_the_foot_of_a_wall(caster, tm
     got = float(img.mean())
     print("AO", "at the foot of a wall" if wall else "open floor", got, "expected", want)
     assert abs(got - want) <= (0.01 if wall else 1e-4) * want
+
+
+def test_path_tracing_light_tracing_and_bidirectional_path_tracing_estimate_the_same_image(caster, tmp_path):
+    """The three integrators of the HIP renderer -- queues (pt), splatting through queues or in place (lt), one
+    kernel per sample with vertex columns in HBM (bdpt) -- on the scene of the oracle's test of the same name."""
+    films = {}
+    for integ, spp in (("pt", 1024), ("lt", 4096), ("bdpt", 512)):
+        sub = tmp_path / integ
+        sub.mkdir()
+        films[integ] = render_mean(caster, ind.lit_floor_scene(str(sub), integ), spp)
+    pt = ind.block_means(films["pt"])
+    lit = pt.sum(axis=2) > 0.1 * pt.sum(axis=2).max()
+    assert lit.sum() >= 8
+    for other in ("lt", "bdpt"):
+        ot = ind.block_means(films[other])
+        ratio = ot[lit].sum() / pt[lit].sum()
+        rel = np.abs(ot - pt).sum(axis=2)[lit] / pt.sum(axis=2)[lit]
+        print(other, "against pt: total", ratio, "median block difference", np.median(rel), "worst", rel.max())
+        assert 0.98 < ratio < 1.02, (other, ratio)
+        assert np.median(rel) < 0.06 and rel.max() < 0.25, (other, rel)   # (block-wise the difference is noise)

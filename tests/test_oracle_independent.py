@@ -440,3 +440,54 @@ def test_thin_lens_rays_of_one_pixel_meet_on_the_plane_of_focus(tmp_path):
         spread = np.linalg.norm(starts, axis=1)
         assert spread.max() <= radius * 1.0001 and spread.max() > 0.6 * radius    # ... all over the aperture disk
         assert np.linalg.norm(crossings - crossings.mean(axis=0), axis=1).max() <= 1.05 * pixel
+
+
+# ------------------------------------------------------------------ three estimators, one image
+def lit_floor_scene(d, integrator):
+    """A Lambertian floor and a box on it under a one-sided rectangular emitter whose back and whose own surface reflect
+    nothing: every path has the same few kinds of vertices, and path tracing, light tracing and bidirectional path
+    tracing -- three different pieces of code, pathtracer.cu:873-1011, 1232-1375, 1379-1956 -- estimate the same image."""
+    quad = np.array([[[-0.7, 2.0, -0.6], [0.6, 2.0, -0.6], [0.6, 2.0, 0.7]], [[-0.7, 2.0, -0.6], [0.6, 2.0, 0.7], [-0.7, 2.0, 0.7]]])
+    write_obj(os.path.join(d, "light.obj"), quad, np.array([[0, -1, 0], [0, -1, 0]], float))
+    floor = np.array([[[-30, 0, 30], [30, 0, 30], [30, 0, -30]], [[-30, 0, 30], [30, 0, -30], [-30, 0, -30]]], float)
+    write_obj(os.path.join(d, "floor.obj"), floor, np.array([[0, 1, 0], [0, 1, 0]], float))
+    c, s = np.array([0.9, 0.4, 0.2]), 0.4
+    P = c + s * np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1]], float)
+    faces = [(0, 3, 2, 1, (0, 0, -1)), (4, 5, 6, 7, (0, 0, 1)), (0, 1, 5, 4, (0, -1, 0)), (2, 3, 7, 6, (0, 1, 0)),
+             (1, 2, 6, 5, (1, 0, 0)), (0, 4, 7, 3, (-1, 0, 0))]
+    tris, nrm = [], []
+    for a, b, cc, dd, n in faces:
+        tris += [[P[a], P[b], P[cc]], [P[a], P[cc], P[dd]]]
+        nrm += [n, n]
+    write_obj(os.path.join(d, "box.obj"), np.array(tris), np.array(nrm, float))
+    w, h = 48, 32
+    doc = {"screen_width": w, "screen_height": h, "integrator": integrator, "maxDepth": 6,
+           "camera": {"position": [0.0, 1.6, 5.0], "lookat": [0.2, 0.3, 0], "up": [0, 1, 0], "fov": 32, "filmicTonemap": False},
+           "material": [{"name": "grey", "bsdf": "lambertian", "diffuse": [0.6, 0.5, 0.4]},
+                        {"name": "black", "bsdf": "lambertian", "diffuse": [0, 0, 0]}],
+           "scene": [{"mesh": "floor.obj", "material": "grey"}, {"mesh": "box.obj", "material": "grey"}],
+           "light": [{"mesh": "light.obj", "material": "black", "radiance": [6, 5, 4]}]}
+    return write_scene(d, doc)
+
+
+def block_means(img, by=8):
+    h, w, _ = img.shape
+    return img[:h // by * by, :w // by * by].reshape(h // by, by, w // by, by, 3).mean(axis=(1, 3))
+
+
+def test_path_tracing_light_tracing_and_bidirectional_path_tracing_estimate_the_same_image(tmp_path):
+    films = {}
+    for integ, spp in (("pt", 512), ("lt", 2048), ("bdpt", 256)):
+        sub = tmp_path / integ
+        sub.mkdir()
+        films[integ] = ol.Oracle(lit_floor_scene(str(sub), integ)).render(1, spp, 8) / spp
+    pt = block_means(films["pt"])
+    lit = pt.sum(axis=2) > 0.1 * pt.sum(axis=2).max()           # blocks that show lit surfaces
+    assert lit.sum() >= 8
+    for other in ("lt", "bdpt"):
+        ot = block_means(films[other])
+        ratio = ot[lit].sum() / pt[lit].sum()
+        rel = np.abs(ot - pt).sum(axis=2)[lit] / pt.sum(axis=2)[lit]
+        print(other, "against pt: total", ratio, "median block difference", np.median(rel), "worst", rel.max())
+        assert 0.97 < ratio < 1.03, (other, ratio)
+        assert np.median(rel) < 0.06 and rel.max() < 0.25, (other, rel)     # (block-wise the difference is noise: light tracing converges slowly)
