@@ -39,7 +39,7 @@ def test_a_convex_body_in_a_uniform_environment_shows_its_albedo(caster, tmp_pat
     assert abs(got - want) <= 0.005 * want, (bsdf, got, want)
 
 
-@pytest.mark.parametrize("boundary", ["matched", "glass"])
+@pytest.mark.parametrize("boundary", ["matched", "glass", "grid"])
 def test_a_scattering_medium_without_absorption_in_a_uniform_environment_shows_one(caster, tmp_path, boundary):
     path, body = ind.volume_furnace_scene(str(tmp_path), boundary)
     sc = caster.Scene(path)

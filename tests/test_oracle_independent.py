@@ -341,7 +341,8 @@ def test_an_emitter_seen_through_an_absorbing_medium_follows_beer_lambert(tmp_pa
 def volume_furnace_scene(d, boundary):
     """A cube of non-absorbing, scattering medium (albedo 1, isotropic) inside an environment of radiance 1: whatever
     the light does inside, radiance 1 comes out.  `boundary`: "matched" (an index-matched surface that only switches
-    the medium, pathtracer.cu:1106-1113) or "glass" (a dielectric surface around the medium)."""
+    the medium, pathtracer.cu:1106-1113), "glass" (a dielectric surface around the medium) or "grid" (the matched
+    boundary around a density grid)."""
     write_constant_pfm(os.path.join(d, "env.pfm"), 1.0)
     c = 0.5
     P = np.array([[-c, -c, -c], [c, -c, -c], [c, c, -c], [-c, c, -c], [-c, -c, c], [c, -c, c], [c, c, c], [-c, c, c]], float)
@@ -355,10 +356,22 @@ def volume_furnace_scene(d, boundary):
     shape = {"mesh": "cube.obj", "inside": "fog", "outside": ""}
     if boundary == "glass":
         shape["material"] = "glass"
+    medium = {"name": "fog", "type": "homogeneous", "sigmaA": [0, 0, 0], "sigmaS": [1.5, 2.5, 4.0], "scale": 1, "g": 0}
+    if boundary == "grid":
+        # a density grid inside the matched boundary (delta tracking for the free flight, ratio tracking for the
+        # transmittance, medium.h:41-129): uneven density, still no absorption
+        n = 6
+        z, y, x = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+        dens = 0.15 + 0.85 * (((x + 2 * y + 3 * z) % 5) / 4.0)
+        with open(os.path.join(d, "density.txt"), "w") as f:
+            for val in dens.reshape(-1):
+                f.write("%.6f\n" % val)
+        medium = {"name": "fog", "type": "heterogeneous", "sigmaA": [0, 0, 0], "sigmaS": [3, 3, 3], "scale": 1, "g": 0,
+                  "nx": n, "ny": n, "nz": n, "p0": [-c, -c, -c], "p1": [c, c, c], "density": "density.txt", "iterMax": 1000}
     w = h = 32
     doc = {"screen_width": w, "screen_height": h, "integrator": "vpt", "maxDepth": 200,
            "camera": {"position": [1.2, 0.9, 3.0], "lookat": [0, 0, 0], "up": [0, 1, 0], "fov": 22, "filmicTonemap": False},
-           "medium": [{"name": "fog", "type": "homogeneous", "sigmaA": [0, 0, 0], "sigmaS": [1.5, 2.5, 4.0], "scale": 1, "g": 0}],
+           "medium": [medium],
            "material": [{"name": "glass", "bsdf": "dielectric", "insideIOR": 1.33, "outsideIOR": 1.0}],
            "scene": [shape],
            "light": [{"infinite": "env.pfm"}]}
@@ -366,7 +379,7 @@ def volume_furnace_scene(d, boundary):
     return write_scene(d, doc), body
 
 
-@pytest.mark.parametrize("boundary", ["matched", "glass"])
+@pytest.mark.parametrize("boundary", ["matched", "glass", "grid"])
 def test_a_scattering_medium_without_absorption_in_a_uniform_environment_shows_one(tmp_path, boundary):
     path, body = volume_furnace_scene(str(tmp_path), boundary)
     o = ol.Oracle(path)
