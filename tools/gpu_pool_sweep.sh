@@ -1,4 +1,4 @@
-# bench line against streams x iterations per batch (pool sizes beyond the default 3 x 32)
+# bench line against streams x iterations per batch (pool sizes about the default 3 x 64)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 : > gpurun_out/pool_sweep.txt
@@ -10,10 +10,13 @@ d = json.loads([l for l in open('gpurun_out/p.json') if l.startswith('{')][-1])
 print('%-28s %8.1f Msamples/s' % (sys.argv[1], d['value']), {k: round(v) for k, v in d['kernel_ms'].items()})
 PY
 done <<'LIST'
-1 192 192
-1 256 256
-2 160 320
-2 176 352
-3 96 288
-3 104 312
+3 64 192
+3 48 144
+3 32 96
+3 24 72
+3 16 48
+4 32 128
+4 16 64
+6 16 96
+3 64 192
 LIST
