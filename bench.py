@@ -426,6 +426,12 @@ def main():
                 "overlapped": {"streams": r_streams, "kernels": per_kernel,
                                "requested_bytes_per_step": pipeline_req / max(a.steps, 1),
                                "requested_rate_gbs": pipeline_req / dt / 1e9,
+                               # HBM-side bytes of the three kernels per second of the timed region (committed PMC
+                               # passes x launches), against the HBM peak: what the whole pipeline draws from memory
+                               "hbm_traffic_rate_gbs": (sum(k["traffic"] * k["launches"] for k in per_kernel) / dt / 1e9
+                                                        if all(k.get("traffic") for k in per_kernel) else None),
+                               "hbm_frac": (sum(k["traffic"] * k["launches"] for k in per_kernel) / dt / 1e9 / HBM_PEAK_GBS
+                                            if all(k.get("traffic") for k in per_kernel) else None),
                                "note": "launch durations of the timed region: several streams share the GPU"}}
         # one-stream repeat: each launch has the GPU to itself
         try:
