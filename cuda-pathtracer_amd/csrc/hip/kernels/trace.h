@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
   __shared__ uint2 s_stack[kTraceBlockWaves][kTraceRays * kLdsDepth][kWave];
   __shared__ float4 s_top[kTopNodes > 0 ? kTopNodes * kTopF4 : 1];
 #ifdef CASTER_WALK_STATS
-  unsigned long long ws[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ws[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const DevScene& S = L.S;
   const uint32_t lane = threadIdx.x & 63u;
@@ -349,6 +349,9 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
         const bool w = kTraceRays == 2 && !leaf_a;
         int pend = pick(w, a.pend, b.pend);
         n_prim_tests += (uint32_t)n_leaf;   // (every lane that holds a leaf tests one primitive)
+#ifdef CASTER_WALK_STATS
+        bool ws_last = true;
+#endif
         if (pend != kRefEmpty) {
           const V3 o = pick(w, a.o, b.o), d = pick(w, a.d, b.d), inv = pick(w, a.inv, b.inv);
           const float maxD = kTraceRays == 2 ? pick(w, a.maxD, b.maxD) : maxabs3(d);   // (one v_max3 against a register held)
@@ -359,6 +362,9 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
           float t, b1, b2;
           bool last;
           bool found = prim_test(S, i, o, d, inv, maxD, tmin, ht, t, b1, b2, last);
+#ifdef CASTER_WALK_STATS
+          ws_last = last;
+#endif
           // (an occlusion ray holds -1 in hit.prim, or the emitter a probe ray was sent to, at
           // distance hit.t: the emitter itself and what it hides at equal distance do not occlude)
           const bool better = found && (t < ht || i > hp);
@@ -388,6 +394,15 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
           put(w, a.cur, b.cur, cur);
           put(w, a.pend, b.pend, pend);
         }
+#ifdef CASTER_WALK_STATS
+        {   // what idle lanes could take over: the next primitive of a lane whose leaf goes on
+          const int n_want = __popcll(lane_ballot(!ws_last));
+          const int n_free = kWave - n_leaf;
+          ws[13] += (unsigned long long)n_want;
+          ws[14] += (unsigned long long)(n_want < n_free ? n_want : n_free);
+          ws[15] += (unsigned long long)n_free;
+        }
+#endif
       }
     }
   }
@@ -401,6 +416,8 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
 #ifdef CASTER_WALK_STATS
   if (lane == 0)
     for (int k = 0; k < 8; ++k) atomicAdd(&g_walk_stats[ANY ? 1 : 0][k], ws[k]);
+  if (lane == 0)
+    for (int k = 13; k < 16; ++k) atomicAdd(&g_walk_stats[ANY ? 1 : 0][k], ws[k]);
   atomicAdd(&g_walk_stats[ANY ? 1 : 0][8], (unsigned long long)st.n_pop_calls);
   atomicAdd(&g_walk_stats[ANY ? 1 : 0][9], (unsigned long long)st.n_pop_iters);
   atomicAdd(&g_walk_stats[ANY ? 1 : 0][10], (unsigned long long)st.n_spill_push);

@@ -22,4 +22,6 @@ for a, name in ((0, "closest"), (1, "any")):
     print("   node steps with a lane on the careful push path %.1f %% (%.1f lanes of them); pops: %.2f entries per call, "
           "%d calls; spilled pushes %d, pops from the spill %d, careful pushes (lanes) %d" % (
               100.0 * v[5] / max(v[0], 1), v[7] / max(v[5], 1), v[9] / max(v[8], 1), v[8], v[10], v[11], v[12]))
+    print("   primitive steps: lanes whose leaf goes on %.1f, lanes without a leaf %.1f, pairs of the two %.1f per step" % (
+        v[13] / max(v[2], 1), v[15] / max(v[2], 1), v[14] / max(v[2], 1)))
 print("rays", st["rays"])
