@@ -1,3 +1,4 @@
+# 32 against 64 iterations per batch (three streams) on four scenes, twice each
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for sc in "stairs_pt 1920 1080 8" "knot_pt 1024 1024 8" "cornell_vpt 1024 1024 16" "car_pt 1920 1080 8"; do
