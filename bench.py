@@ -458,6 +458,10 @@ def main():
             roof["exclusive"] = {"streams": 1, "msamples_per_s": st1["samples"] / dt1 / 1e6, "kernels": ex,
                                  "requested_rate_gbs": sum(k["requested_bytes_per_launch"] * k["launches"] for k in ex) / dt1 / 1e9}
             roof["duration"] = "one-stream repeat after the timed region (a launch has the GPU to itself)"
+            if dom.get("pmc"):
+                roof["note"] = ("bytes against the roof of the memory level that serves them; what fills first in this kernel is "
+                                "vector-instruction issue (pmc.valu_issue_busy %.2f of the launch), and in the pipeline as a "
+                                "whole too (valu_issue)" % dom["pmc"]["valu_issue_busy"])
         except caster.CasterError as e:
             dom = max(per_kernel, key=lambda k: k["total_ms"])
             roof.update({k: v for k, v in dom.items()})
