@@ -5,10 +5,10 @@
 // sphere.h:74-80, pathtracer.cu:127-147, cutil_math.h:1197-1201).  Those are
 // only specified to a few ulp, so two conforming builds of the reference
 // already differ in the last bit.  This header pins every such function to
-// one sequence of IEEE-754 binary32 add/mul/div/sqrt operations (no fused
-// multiply-add; translation units that include it are built with
-// -ffp-contract=off) so that an x86 build and a gfx950 build produce the same
-// bits for the same inputs.  On the domain the render path uses every
+// one sequence of IEEE-754 binary32 add/mul/div/sqrt operations (translation
+// units that include it are built with -ffp-contract=off; the only fused
+// multiply-adds are the ones written out with fma_() below) so that an x86
+// build and a gfx950 build produce the same bits for the same inputs.  On the domain the render path uses every
 // function is within 3 ulp of the exact value (sin_/cos_ within 1e-13
 // absolute next to their zeros, pow_ within 6 ulp); tests/test_fpspec.py
 // checks that against double-precision libm.
@@ -38,6 +38,38 @@ CASTER_HD float fmax_(float a, float b) { return (a > b || b != b) ? a : b; }
 CASTER_HD float rsqrt_(float x) { return 1.0f / sqrtf(x); }
 
 CASTER_HD float clamp_(float v, float lo, float hi) { return fmin_(fmax_(v, lo), hi); }
+
+// ---- fused multiply-add ----------------------------------------------------
+// The reference is built with nvcc's default -fmad=true, so its own binary evaluates the dot
+// and cross products of cutil_math.h:1132-1140, 1308-1311 with fused multiply-adds.  The
+// translation units here are built with contraction OFF (an x86 compiler and the gfx950 compiler
+// would not fuse the same operations), and the places that are fused are written out with
+// fma_(), the same on both sides: exactly rounded on either machine (x86: vfmadd, the host
+// objects are built with -mfma; gfx950: v_fma_f32), so the results stay equal bit for bit.
+//   dot:    a.x*b.x + a.y*b.y + a.z*b.z   ->  fma(a.z, b.z, fma(a.x, b.x, a.y*b.y))
+//   cross:  a*b - c*d                     ->  fma(a, b, -(c*d))
+// which is how the compiler behind nvcc contracts those expressions (the first product of a sum
+// becomes the multiplicand of the fma that adds the second; a difference of products keeps its
+// second product rounded).
+CASTER_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+CASTER_HD float dot3_(float ax, float ay, float az, float bx, float by, float bz) {
+  return fma_(az, bz, fma_(ax, bx, ay * by));
+}
+CASTER_HD float diffprod_(float a, float b, float c, float d) { return fma_(a, b, -(c * d)); }
+
+// One plane of the slab test (bbox.h:76-84: (plane - origin) * (1 / direction)), for a ray that carries
+// noi = -(origin * inv) per axis.  FUSED: fma(plane, inv, noi) -- one rounding of (plane - origin) * inv
+// where the reference makes two; that form is monotone in `plane` like the reference's (a single rounding
+// of a monotone function), so a box inside another is still entered no earlier and left no later than the
+// outer one, which is all the traversal relies on.  A ray whose noi is not finite in some component (a
+// direction component of zero, a non-finite origin, or origin * inv overflowing) keeps the reference's form
+// for all its box tests: there inf - inf would make planes vanish from the test.
+CASTER_HD bool slab_fused_(float noix, float noiy, float noiz) {
+  return fabsf(noix) < INFINITY && fabsf(noiy) < INFINITY && fabsf(noiz) < INFINITY;
+}
+CASTER_HD float slab_plane_(float plane, float o, float inv, float noi, bool fused) {
+  return fused ? fma_(plane, inv, noi) : (plane - o) * inv;
+}
 
 // Slack of the slab test's near-plane cull.  The reference drops a box whose entry distance
 // exceeds the ray's tmax (CUDA-PathTracer/tracer/bbox.h:88-97: the far side is padded by

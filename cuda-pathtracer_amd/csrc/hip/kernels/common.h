@@ -57,9 +57,10 @@ __device__ inline V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z 
 __device__ inline V3 operator+(V3 a, float s) { return V3{a.x + s, a.y + s, a.z + s}; }
 __device__ inline V3 operator-(V3 a, float s) { return V3{a.x - s, a.y - s, a.z - s}; }
 __device__ inline V3 operator-(float s, V3 a) { return V3{s - a.x, s - a.y, s - a.z}; }
-__device__ inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// (fused as nvcc's default contraction fuses cutil_math.h:1136, 1308: see fpspec.h)
+__device__ inline float dot(V3 a, V3 b) { return fps::dot3_(a.x, a.y, a.z, b.x, b.y, b.z); }
 __device__ inline V3 cross(V3 a, V3 b) {
-  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+  return V3{fps::diffprod_(a.y, b.z, a.z, b.y), fps::diffprod_(a.z, b.x, a.x, b.z), fps::diffprod_(a.x, b.y, a.y, b.x)};
 }
 __device__ inline float length(V3 v) { return sqrtf(dot(v, v)); }
 __device__ inline V3 normalize(V3 v) { return v * fps::rsqrt_(dot(v, v)); }

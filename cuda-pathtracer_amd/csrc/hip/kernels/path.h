@@ -233,8 +233,7 @@ __device__ inline void shade_pt_vertices(const LaunchCtx& L, const RayQueue& cur
               // first the padded box around all emitters: a ray that misses it cannot hit one
               float tn;
               bool reach = S.n_lights > 0 &&
-                           box_test(v3(S.emit_lo), v3(S.emit_hi), pos, v3(1.f / mo.x, 1.f / mo.y, 1.f / mo.z), INFINITY,
-                                    S.box_scale, tn);
+                           box_test(v3(S.emit_lo), v3(S.emit_hi), slab_ray(pos, mo), INFINITY, S.box_scale, tn);
               if (!reach) {
                 want_probe = false;
                 py = make_float4(0, 0, 0, 0);

@@ -123,8 +123,14 @@ __device__ unsigned long long g_walk_stats[2][16];
 #define CASTER_WS(i, v)
 #endif
 // One ray of a lane.
+#ifndef CASTER_WALK_KEEP_NOI
+#define CASTER_WALK_KEEP_NOI 1   // 1: a ray keeps -(origin / direction) in registers; 0: three multiplies in every node step
+#endif
 struct WalkRay {
   V3 o, d, inv;
+#if CASTER_WALK_KEEP_NOI
+  V3 noi;    // -(o * inv), the addend of the fused slab test
+#endif
   float maxD;
   Hit hit;
   int idx;   // queue entry; -1: the slot is free
@@ -132,11 +138,26 @@ struct WalkRay {
   int pend;  // a leaf waiting for its primitives to be tested (same encoding), kRefEmpty
   int sp;    // height of its stack
   int occluded;
-  Octant oct;  // direction octant (node_step<.., OCT>); kOctPlain where 1 / direction or the origin is not finite in
-               // some component: the ray keeps to the plain slab test
+  Octant oct;  // direction octant (node_step<.., OCT>); kOctPlain where origin / direction is not finite in
+               // some component: the ray keeps to the plain slab test in the reference's form
 };
+// What the slab test wants of ray `r`.
+__device__ inline SlabRay slab_of(const WalkRay& r) {
+  SlabRay s;
+  s.o = r.o; s.inv = r.inv;
+#if CASTER_WALK_KEEP_NOI
+  s.noi = r.noi;
+#else
+  s.noi = v3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
+#endif
+  s.fused = (r.oct.b & kOctPlain) == 0u;
+  return s;
+}
 __device__ inline void walk_ray_idle(WalkRay& r) {
   r.o = v3(0, 0, 0); r.d = v3(0, 0, 1); r.inv = v3(0, 0, 1); r.maxD = 1.f;
+#if CASTER_WALK_KEEP_NOI
+  r.noi = v3(0, 0, 0);
+#endif
   r.hit.t = 0.f; r.hit.prim = -1; r.hit.b1 = r.hit.b2 = 0.f;
   r.idx = -1; r.cur = kRefEmpty; r.pend = kRefEmpty; r.sp = 0; r.occluded = 0;
   r.oct = Octant{0u, 0u};
@@ -147,11 +168,11 @@ __device__ inline V3 pick(bool second, V3 x0, V3 x1) { return v3(pick(second, x0
 __device__ inline void put(bool second, float& x0, float& x1, float v) { x0 = second ? x0 : v; x1 = second ? v : x1; }
 __device__ inline void put(bool second, int& x0, int& x1, int v) { x0 = second ? x0 : v; x1 = second ? v : x1; }
 
-// (registers are budgeted for one wavefront per SIMD more than the grid brings: at 80 the kernel leaves room for
-// two wavefronts of a shade kernel beside four of its own, at 96 for one -- which is what the small scenes, where
-// the streams' kernels really run side by side, notice)
+// (registers: the budget of the wavefronts the grid brings, 96 at five per SIMD.  With the fused slab test a ray
+// carries three registers more, and at 80 -- room for a sixth wavefront, of another stream's shade kernel -- five
+// values were spilled and read back inside the step loop: 1735 against 1830 Msamples/s on the benchmark scene)
 #ifndef CASTER_TRACE_REG_WAVES
-#define CASTER_TRACE_REG_WAVES (CASTER_TRACE_WAVES + 1)
+#define CASTER_TRACE_REG_WAVES CASTER_TRACE_WAVES
 #endif
 template <bool ANY>
 __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) void k_trace(LaunchCtx L, RayQueue q, WalkAux aux) {
@@ -264,9 +285,11 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
       r.o = v3(o4); r.d = v3(d4);
       r.inv = v3(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
       r.maxD = maxabs3(r.d);
-      r.oct = octant_of(r.inv, CASTER_OCTANT_GUARD &&
-                               !(fabsf(r.inv.x) < INFINITY && fabsf(r.inv.y) < INFINITY && fabsf(r.inv.z) < INFINITY &&
-                                 fabsf(r.o.x) < INFINITY && fabsf(r.o.y) < INFINITY && fabsf(r.o.z) < INFINITY));
+      const V3 noi = v3(-(r.o.x * r.inv.x), -(r.o.y * r.inv.y), -(r.o.z * r.inv.z));
+#if CASTER_WALK_KEEP_NOI
+      r.noi = noi;
+#endif
+      r.oct = octant_of(r.inv, CASTER_OCTANT_GUARD && !fps::slab_fused_(noi.x, noi.y, noi.z));
       // every queued ray starts at the scene's epsilon; o.w carries a hit known
       // beforehand (a probe ray's nearest emitter, at distance tmax) or -1
       r.hit.t = d4.w; r.hit.prim = __float_as_int(o4.w); r.hit.b1 = r.hit.b2 = 0.f;
@@ -327,13 +350,13 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
         // (one ray in 10^7 is parallel to an axis; the whole step then takes the plain slab test)
         const bool plain_step = !CASTER_OCTANT_BOXES || any_lane(cur >= 0 && ((kTraceRays == 2 ? (a.oct.b | b.oct.b) : a.oct.b) & kOctPlain) != 0);
         if (cur >= 0) {
-          const V3 o = pick(w, a.o, b.o), inv = pick(w, a.inv, b.inv);
+          const SlabRay sr = slab_of(kTraceRays == 2 && w ? b : a);
           const float tmax = pick(w, a.hit.t, b.hit.t);
           int pend = pick(w, a.pend, b.pend);
           st.sp = pick(w, a.sp, b.sp);
           st.ctx = w ? 1 : 0;
-          if (plain_step) cur = node_step<!ANY || !CASTER_ANY_UNSORTED, false>(S, cur, o, inv, tmax, st, lane, overflow, s_top, n_top);
-          else cur = node_step<!ANY || !CASTER_ANY_UNSORTED, true>(S, cur, o, inv, tmax, st, lane, overflow, s_top, n_top,
+          if (plain_step) cur = node_step<!ANY || !CASTER_ANY_UNSORTED, false>(S, cur, sr, tmax, st, lane, overflow, s_top, n_top);
+          else cur = node_step<!ANY || !CASTER_ANY_UNSORTED, true>(S, cur, sr, tmax, st, lane, overflow, s_top, n_top,
                                                                    kTraceRays == 2 && w ? b.oct : a.oct);
           if (cur < 0 && cur != kRefEmpty && pend == kRefEmpty) {
             pend = cur;
@@ -353,7 +376,8 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
         bool ws_last = true;
 #endif
         if (pend != kRefEmpty) {
-          const V3 o = pick(w, a.o, b.o), d = pick(w, a.d, b.d), inv = pick(w, a.inv, b.inv);
+          const SlabRay sr = slab_of(kTraceRays == 2 && w ? b : a);
+          const V3 d = pick(w, a.d, b.d);
           const float maxD = kTraceRays == 2 ? pick(w, a.maxD, b.maxD) : maxabs3(d);   // (one v_max3 against a register held)
           float ht = pick(w, a.hit.t, b.hit.t);
           const int hp = pick(w, a.hit.prim, b.hit.prim);
@@ -361,7 +385,7 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
           int i = ~pend;
           float t, b1, b2;
           bool last;
-          bool found = prim_test(S, i, o, d, inv, maxD, tmin, ht, t, b1, b2, last);
+          bool found = prim_test(S, i, sr, d, maxD, tmin, ht, t, b1, b2, last);
 #ifdef CASTER_WALK_STATS
           ws_last = last;
 #endif

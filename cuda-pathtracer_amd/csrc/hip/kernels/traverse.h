@@ -5,16 +5,31 @@
 namespace caster {
 
 // --------------------------------------------------------------- traversal
+// What the slab test needs of a ray: origin, 1 / direction, noi = -(origin * inv), and whether the test is made
+// with one fused multiply-add per plane (fps::slab_plane_: every ray whose noi is finite) or in the reference's
+// own form.
+struct SlabRay {
+  V3 o, inv, noi;
+  bool fused;
+};
+__device__ inline SlabRay slab_ray(V3 o, V3 d) {
+  SlabRay r;
+  r.o = o;
+  r.inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  r.noi = v3(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+  r.fused = fps::slab_fused_(r.noi.x, r.noi.y, r.noi.z);
+  return r;
+}
 // Slab test of the reference (bbox.h:75-98): tFar widened by 1+2*gamma(3),
 // rejected when behind the ray, empty, or beyond the current tmax; tmin is
 // not consulted.  Returns tNear through `tn`.
-__device__ inline bool box_test(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float scale, float& tn) {
-  float txNear = (lo.x - o.x) * inv.x;
-  float txFar = (hi.x - o.x) * inv.x;
-  float tyNear = (lo.y - o.y) * inv.y;
-  float tyFar = (hi.y - o.y) * inv.y;
-  float tzNear = (lo.z - o.z) * inv.z;
-  float tzFar = (hi.z - o.z) * inv.z;
+__device__ inline bool box_test(V3 lo, V3 hi, const SlabRay& r, float tmax, float scale, float& tn) {
+  float txNear = fps::slab_plane_(lo.x, r.o.x, r.inv.x, r.noi.x, r.fused);
+  float txFar = fps::slab_plane_(hi.x, r.o.x, r.inv.x, r.noi.x, r.fused);
+  float tyNear = fps::slab_plane_(lo.y, r.o.y, r.inv.y, r.noi.y, r.fused);
+  float tyFar = fps::slab_plane_(hi.y, r.o.y, r.inv.y, r.noi.y, r.fused);
+  float tzNear = fps::slab_plane_(lo.z, r.o.z, r.inv.z, r.noi.z, r.fused);
+  float tzFar = fps::slab_plane_(hi.z, r.o.z, r.inv.z, r.noi.z, r.fused);
   // v_min_f32 / v_max_f32 drop a NaN operand exactly as fps::fmin_/fmax_ do;
   // they may differ in the sign of a zero result, which no comparison below sees.
   float tNear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(txNear, txFar), __builtin_fminf(tyNear, tyFar)),
@@ -37,25 +52,27 @@ struct Hit {
 // edge vectors and coordinate maxima precomputed per primitive (the same
 // float operations, done once on the host).  Sphere: sphere.h:24-66.  Line:
 // line.h:33-72.
-__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, V3 inv, float maxD, float tmin,
-                                     float tmax, float& t, float& ob1, float& ob2, bool& last);
-// (`inv` = 1 / d per component, which the walkers hold anyway: the sphere test wants it for its box)
-__device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, V3 inv, float maxD, float tmin, float tmax,
+// (`sr` holds the ray's origin and what the slab test wants, which the walkers hold anyway: the sphere
+// test consults the sphere's own box)
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, const SlabRay& sr, V3 d, float maxD,
+                                     float tmin, float tmax, float& t, float& ob1, float& ob2, bool& last);
+__device__ inline bool prim_test(const DevScene& S, int i, const SlabRay& sr, V3 d, float maxD, float tmin, float tmax,
                                  float& t, float& ob1, float& ob2, bool& last) {
   const float4* rec = S.isect + (size_t)i * kIsectF4;
-  return prim_test_rec(S, rec[0], rec[1], rec[2], o, d, inv, maxD, tmin, tmax, t, ob1, ob2, last);
+  return prim_test_rec(S, rec[0], rec[1], rec[2], sr, d, maxD, tmin, tmax, t, ob1, ob2, last);
 }
 __device__ inline bool prim_test(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, float tmax,
                                  float& t, float& ob1, float& ob2, bool& last) {
-  return prim_test(S, i, o, d, v3(1.f / d.x, 1.f / d.y, 1.f / d.z), maxD, tmin, tmax, t, ob1, ob2, last);
+  return prim_test(S, i, slab_ray(o, d), d, maxD, tmin, tmax, t, ob1, ob2, last);
 }
 __device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, float maxD, float tmin,
                                      float tmax, float& t, float& ob1, float& ob2, bool& last) {
-  return prim_test_rec(S, a, b, c, o, d, v3(1.f / d.x, 1.f / d.y, 1.f / d.z), maxD, tmin, tmax, t, ob1, ob2, last);
+  return prim_test_rec(S, a, b, c, slab_ray(o, d), d, maxD, tmin, tmax, t, ob1, ob2, last);
 }
 // The same test on a record already in registers.
-__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, V3 o, V3 d, V3 inv, float maxD, float tmin,
-                                     float tmax, float& t, float& ob1, float& ob2, bool& last) {
+__device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, float4 c, const SlabRay& sr, V3 d, float maxD,
+                                     float tmin, float tmax, float& t, float& ob1, float& ob2, bool& last) {
+  const V3 o = sr.o;
   uint32_t bits = __float_as_uint(c.w);
   last = (bits & kPrimLastInLeaf) != 0;
   uint32_t type = bits & kPrimTypeMask;
@@ -115,7 +132,7 @@ __device__ inline bool prim_test_rec(const DevScene& S, float4 a, float4 b, floa
     // entry of every box above it, so it is tested whenever it could still win, whatever the
     // order the tree is walked in.
     float tn;
-    (void)box_test(v3(a) - radius, v3(a) + radius, o, inv, INFINITY, S.box_scale, tn);
+    (void)box_test(v3(a) - radius, v3(a) + radius, sr, INFINITY, S.box_scale, tn);
     if (tn > th * fps::kNearCullSlack) return false;
     t = th; ob1 = 0.f; ob2 = 0.f;
     return true;
@@ -285,17 +302,19 @@ __device__ inline uint32_t add_byte(uint32_t base, uint32_t packed) {
   if (K == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(packed));
   return r;
 }
-// Such a ray's slab test when 1 / direction is finite in every component: the nearer of an axis's two planes is
-// then known from the sign alone -- for lo <= hi, (lo - o) * inv <= (hi - o) * inv when inv > 0 and >= when inv < 0,
-// rounding included, since subtraction and multiplication by a finite number are monotone -- so the six minima and
-// maxima of box_test() fall away and the results are the same bit for bit.  (An empty child slot, lo = +inf and
-// hi = -inf, gives tNear = +inf and tFar = -inf here and fails without a look at its reference.)  With an
-// infinite component, (plane - o) * inv is not a number where the origin lies in the plane, box_test()'s minima
-// and maxima drop that operand, and which one they drop decides: such rays keep to box_test().
-__device__ inline bool box_test_octant(float nx, float ny, float nz, float fx, float fy, float fz, V3 o, V3 inv,
+// Such a ray's slab test when its test is the fused one (finite 1 / direction, origin and their product): the
+// nearer of an axis's two planes is then known from the sign alone -- for lo <= hi, fma(lo, inv, noi) <=
+// fma(hi, inv, noi) when inv > 0 and >= when inv < 0, rounding included, since a single rounding of a monotone
+// function is monotone -- so the six minima and maxima of box_test() fall away and the results are the same bit
+// for bit.  (An empty child slot, lo = +inf and hi = -inf, gives tNear = +inf and tFar = -inf here and fails
+// without a look at its reference.)  With an infinite component, (plane - o) * inv is not a number where the
+// origin lies in the plane, box_test()'s minima and maxima drop that operand, and which one they drop decides:
+// such rays keep to box_test() and the reference's form of the test.
+__device__ inline bool box_test_octant(float nx, float ny, float nz, float fx, float fy, float fz, V3 inv, V3 noi,
                                        float tmax_slack, float scale, float& tn) {
-  float tNear = __builtin_fmaxf(__builtin_fmaxf((nx - o.x) * inv.x, (ny - o.y) * inv.y), (nz - o.z) * inv.z);
-  float tFar = __builtin_fminf(__builtin_fminf((fx - o.x) * inv.x, (fy - o.y) * inv.y), (fz - o.z) * inv.z);
+  using fps::fma_;
+  float tNear = __builtin_fmaxf(__builtin_fmaxf(fma_(nx, inv.x, noi.x), fma_(ny, inv.y, noi.y)), fma_(nz, inv.z, noi.z));
+  float tFar = __builtin_fminf(__builtin_fminf(fma_(fx, inv.x, noi.x), fma_(fy, inv.y, noi.y)), fma_(fz, inv.z, noi.z));
   tFar *= scale;
   tn = tNear;
   return !(tFar <= 0.00001f) && !(tNear > tFar) && !(tNear > tmax_slack);
@@ -306,7 +325,7 @@ __device__ inline float4 node_f4(const DevScene& S, uint32_t byte_offset) {
 }
 // OCT: the lane's ray has finite reciprocal direction and origin, `oct` is its octant (k_trace sees to both).
 template <bool SORT = true, bool OCT = false>
-__device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float tmax, Stack& st, uint32_t lane,
+__device__ inline int node_step(const DevScene& S, int cur, const SlabRay& sr, float tmax, Stack& st, uint32_t lane,
                                 unsigned long long* overflow, const float4* top = nullptr, int n_top = 0,
                                 Octant oct = Octant{0u, 0u}) {
   float4 rf;
@@ -329,10 +348,10 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
       rf = node_f4(S, b + 96u);
     }
     const float ts = tmax * fps::kNearCullSlack;
-    h0 = box_test_octant(ax.x, ay.x, az.x, bx.x, by.x, bz.x, o, inv, ts, S.box_scale, k0);
-    h1 = box_test_octant(ax.y, ay.y, az.y, bx.y, by.y, bz.y, o, inv, ts, S.box_scale, k1);
-    h2 = box_test_octant(ax.z, ay.z, az.z, bx.z, by.z, bz.z, o, inv, ts, S.box_scale, k2);
-    h3 = box_test_octant(ax.w, ay.w, az.w, bx.w, by.w, bz.w, o, inv, ts, S.box_scale, k3);
+    h0 = box_test_octant(ax.x, ay.x, az.x, bx.x, by.x, bz.x, sr.inv, sr.noi, ts, S.box_scale, k0);
+    h1 = box_test_octant(ax.y, ay.y, az.y, bx.y, by.y, bz.y, sr.inv, sr.noi, ts, S.box_scale, k1);
+    h2 = box_test_octant(ax.z, ay.z, az.z, bx.z, by.z, bz.z, sr.inv, sr.noi, ts, S.box_scale, k2);
+    h3 = box_test_octant(ax.w, ay.w, az.w, bx.w, by.w, bz.w, sr.inv, sr.noi, ts, S.box_scale, k3);
     r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
   } else {
     float4 lx, ly, lz, hx, hy, hz;
@@ -345,10 +364,10 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
       lx = n[0]; ly = n[1]; lz = n[2]; hx = n[3]; hy = n[4]; hz = n[5]; rf = n[6];
     }
     r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
-    h0 = box_test(v3(lx.x, ly.x, lz.x), v3(hx.x, hy.x, hz.x), o, inv, tmax, S.box_scale, k0) && r0 != kRefEmpty;
-    h1 = box_test(v3(lx.y, ly.y, lz.y), v3(hx.y, hy.y, hz.y), o, inv, tmax, S.box_scale, k1) && r1 != kRefEmpty;
-    h2 = box_test(v3(lx.z, ly.z, lz.z), v3(hx.z, hy.z, hz.z), o, inv, tmax, S.box_scale, k2) && r2 != kRefEmpty;
-    h3 = box_test(v3(lx.w, ly.w, lz.w), v3(hx.w, hy.w, hz.w), o, inv, tmax, S.box_scale, k3) && r3 != kRefEmpty;
+    h0 = box_test(v3(lx.x, ly.x, lz.x), v3(hx.x, hy.x, hz.x), sr, tmax, S.box_scale, k0) && r0 != kRefEmpty;
+    h1 = box_test(v3(lx.y, ly.y, lz.y), v3(hx.y, hy.y, hz.y), sr, tmax, S.box_scale, k1) && r1 != kRefEmpty;
+    h2 = box_test(v3(lx.z, ly.z, lz.z), v3(hx.z, hy.z, hz.z), sr, tmax, S.box_scale, k2) && r2 != kRefEmpty;
+    h3 = box_test(v3(lx.w, ly.w, lz.w), v3(hx.w, hy.w, hz.w), sr, tmax, S.box_scale, k3) && r3 != kRefEmpty;
   }
   if (!(h0 || h1 || h2 || h3)) return stack_next_of<SORT>(st, lane, tmax);
   [[maybe_unused]] const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
@@ -493,11 +512,11 @@ __device__ inline int node_step(const DevScene& S, int cur, V3 o, V3 inv, float 
 // distance the higher primitive index wins, as in the reference's in-order
 // scan with its `t <= tmax` acceptance.  ANY: returns at the first hit.
 template <bool ANY>
-__device__ inline bool leaf_step(const DevScene& S, int i, V3 o, V3 d, float maxD, float tmin, Hit& hit) {
+__device__ inline bool leaf_step(const DevScene& S, int i, const SlabRay& sr, V3 d, float maxD, float tmin, Hit& hit) {
   bool last;
   do {
     float t, b1, b2;
-    if (prim_test(S, i, o, d, maxD, tmin, hit.t, t, b1, b2, last)) {
+    if (prim_test(S, i, sr, d, maxD, tmin, hit.t, t, b1, b2, last)) {
       if (ANY) return true;
       if (t < hit.t || i > hit.prim) { hit.t = t; hit.prim = i; hit.b1 = b1; hit.b2 = b2; }
     }
@@ -511,7 +530,7 @@ template <bool ANY>
 __device__ inline bool traverse(const DevScene& S, V3 o, V3 d, float tmin, float tmax, Hit& hit, Stack& st,
                                 unsigned long long* overflow) {
   const uint32_t lane = threadIdx.x & 63u;
-  V3 inv = v3(1.f / d.x, 1.f / d.y, 1.f / d.z);
+  const SlabRay sr = slab_ray(o, d);
   float maxD = maxabs3(d);
   hit.prim = -1;
   hit.t = tmax;
@@ -520,9 +539,9 @@ __device__ inline bool traverse(const DevScene& S, V3 o, V3 d, float tmin, float
   int cur = S.n_nodes ? 0 : kRefEmpty;
   while (cur != kRefEmpty) {
     if (cur >= 0) {
-      cur = node_step(S, cur, o, inv, hit.t, st, lane, overflow);
+      cur = node_step(S, cur, sr, hit.t, st, lane, overflow);
     } else {
-      if (leaf_step<ANY>(S, ~cur, o, d, maxD, tmin, hit)) return true;
+      if (leaf_step<ANY>(S, ~cur, sr, d, maxD, tmin, hit)) return true;
       cur = stack_next(st, lane, hit.t);
     }
   }

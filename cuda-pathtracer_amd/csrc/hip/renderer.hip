@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -37,6 +38,7 @@ static __device__ __align__(256) unsigned char scratch[caster::kStaticScratchByt
 namespace caster {
 
 static thread_local std::string g_last_error;
+static thread_local bool g_out_of_memory = false;   // the calling thread's latest failed allocation ran out of device memory
 
 static int fail(int code, const std::string& msg) {
   g_last_error = msg;
@@ -53,9 +55,11 @@ static int fail(int code, const std::string& msg) {
 // Device address of `scratch` on each GPU (every device holds its own copy at its own address).
 constexpr int kMaxDevices = 64;
 static void* g_static_scratch[kMaxDevices] = {nullptr};
+static std::mutex g_static_scratch_mutex;   // (caster_begin_multi starts one host thread per part, and parts may share a device)
 // Looks the address up on first use for `device`, which must be the current device.
 static int static_scratch_of(int device, void** out) {
   if (device < 0 || device >= kMaxDevices) return fail(CASTER_ERR_ARG, "device index beyond the static scratch table");
+  std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
   if (!g_static_scratch[device]) {
     void* p = nullptr;
     HIPCHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
@@ -227,8 +231,10 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
     const Light& l = sc.lights[i];
     const Prim& p = sc.prims[l.prim];
     f3 e1 = p.v[1].v - p.v[0].v, e2 = p.v[2].v - p.v[0].v;
-    f3 c = cross3(e1, e2);
-    float area = sqrtf(dot3(c, c)) * 0.5f;  // Triangle.h:81-85
+    // Triangle.h:81-85 as the device evaluates it (dot and cross fused, fpspec.h): the kernels read this value where the
+    // reference's device code calls Area(); the light distribution, built on the host, keeps the unfused scene.h form
+    f3 c = f3{fps::diffprod_(e1.y, e2.z, e1.z, e2.y), fps::diffprod_(e1.z, e2.x, e1.x, e2.z), fps::diffprod_(e1.x, e2.y, e1.y, e2.x)};
+    float area = sqrtf(fps::dot3_(c.x, c.y, c.z, c.x, c.y, c.z)) * 0.5f;
     float4* d = &A.lights[i * kLightF4];
     d[0] = mk4(p.v[0].v, area);
     d[1] = mk4(p.v[1].v, l.radiance.x);
@@ -377,7 +383,13 @@ template <class T>
 static int dev_alloc(caster_renderer* r, T** out, size_t count) {
   void* p = nullptr;
   size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-  HIPCHECK(hipMalloc(&p, bytes));
+  {
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      g_out_of_memory = e == hipErrorOutOfMemory;
+      return fail(CASTER_ERR_DEVICE, "hipMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+    }
+  }
   r->allocs.push_back(p);
   *out = (T*)p;
   return CASTER_OK;
@@ -979,16 +991,19 @@ int caster_begin_streams(const caster_scene* s, int device_id, int iters_in_flig
     if (p.mat < 0 && s->scene.integrator == IT_PT)
       return fail(CASTER_ERR_SCENE, "caster_begin: a shape without a material needs the vpt integrator");
   caster_renderer* r = new caster_renderer();
+  g_out_of_memory = false;
   int rc = begin_impl(s->scene, device_id, iters_in_flight, n_streams, r);
   // Default pools are sized from the memory that is free at that moment; when another renderer took its share
   // in the meantime (several processes on one GPU), the allocation fails and the pools are halved until they fit.
-  while (rc == CASTER_ERR_DEVICE && iters_in_flight <= 0 && r->iters_in_flight > 1) {
+  // (Only a failed allocation is tried again: any other device error is reported as it is.)
+  while (rc == CASTER_ERR_DEVICE && g_out_of_memory && iters_in_flight <= 0 && r->iters_in_flight > 1) {
     const int smaller = r->iters_in_flight / 2;
     const int streams = (int)r->lanes.size();
     std::string keep = g_last_error;
     caster_end(r);
     (void)hipGetLastError();   // (the failed allocation is not to be found by the next launch check)
     r = new caster_renderer();
+    g_out_of_memory = false;
     rc = begin_impl(s->scene, device_id, smaller, streams, r);
     if (rc == CASTER_ERR_DEVICE && smaller == 1) { g_last_error = keep; break; }
     if (rc == CASTER_ERR_DEVICE) r->iters_in_flight = smaller;   // (so that the next round halves again)
@@ -1506,14 +1521,18 @@ static int for_each_part(caster_renderer* g, Fn fn) {
   return CASTER_OK;
 }
 
-// Iterations [first, first + n) as part `k` of `world` renders them under spp sharding: blocks of `block`
-// iterations dealt round-robin, as sharding.spp_blocks deals them to ranks.
+// Iterations [first, first + n) as part `k` of `world` renders them under spp sharding: iteration i (counted
+// from 1) lies in block (i - 1) / block, and the blocks are dealt round-robin by that absolute number, as
+// sharding.spp_blocks deals them to ranks -- so who renders an iteration does not depend on how the caller
+// cuts its calls, and a caller that asks for one iteration per call still rotates over the devices.
 static void spp_blocks_of(uint32_t first, uint32_t n, uint32_t block, int k, int world, std::vector<std::pair<uint32_t, uint32_t>>& out) {
-  uint32_t it = first, end = first + n;
-  for (uint32_t b = 0; it < end; ++b) {
-    uint32_t m = std::min(block, end - it);
-    if ((int)(b % (uint32_t)world) == k) out.push_back({it, m});
-    it += m;
+  const uint64_t end = (uint64_t)first + n;
+  uint64_t it = first;
+  while (it < end) {
+    const uint64_t b = (it > 0 ? it - 1 : 0) / block;
+    const uint64_t block_end = std::min<uint64_t>(end, (b + 1) * (uint64_t)block + 1);
+    if ((int)(b % (uint64_t)world) == k) out.push_back({(uint32_t)it, (uint32_t)(block_end - it)});
+    it = block_end;
   }
 }
 
@@ -1539,6 +1558,11 @@ int caster_begin_multi(const caster_scene* s, const int* device_ids, int n_dev, 
     g->device = p0->device;
     g->S = p0->S_full;
     g->iters_in_flight = p0->iters_in_flight;
+    // One block size for the whole group: the parts size their default pools from the memory free on their
+    // device at that moment, so their batches may differ, and parts that cut the iterations into blocks of
+    // different sizes would render some iterations twice and others never.
+    g->batch_iters = p0->batch_iters;
+    for (caster_renderer* p : g->parts) g->batch_iters = std::min(g->batch_iters, p->batch_iters);
     if (hipSetDevice(p0->device) != hipSuccess) rc = fail(CASTER_ERR_DEVICE, "caster_begin_multi: hipSetDevice failed");
     const size_t n = (size_t)g->S.width * g->S.height * 3;
     if (!rc) rc = dev_alloc(p0, &g->group_sum, n);
@@ -1564,7 +1588,7 @@ static int multi_render_async(caster_renderer* g, uint32_t first_iter, uint32_t 
     caster_renderer* p = g->parts[(size_t)i];
     if (g->shard_mode == CASTER_SHARD_TILE) return caster_render_async(p, first_iter, n_iter, reset);
     std::vector<std::pair<uint32_t, uint32_t>> blocks;
-    spp_blocks_of(first_iter, n_iter, (uint32_t)std::max(p->batch_iters, 1), i, world, blocks);
+    spp_blocks_of(first_iter, n_iter, (uint32_t)std::max(g->batch_iters, 1), i, world, blocks);
     if (blocks.empty()) return reset ? caster_render_async(p, first_iter, 0, 1) : (int)CASTER_OK;
     int r1 = CASTER_OK;
     for (size_t b = 0; b < blocks.size() && !r1; ++b) r1 = caster_render_async(p, blocks[b].first, blocks[b].second, b == 0 ? reset : 0);

@@ -24,20 +24,22 @@ Nothing here touches a device: the functions take and return plain numbers and
 
 
 def spp_blocks(first_iter, n_iter, block, rank, world):
-    """Contiguous iteration blocks (first, count) of [first_iter, first_iter + n_iter)
-    that `rank` renders: block b of size `block` goes to rank b % world."""
+    """Contiguous iteration ranges (first, count) of [first_iter, first_iter + n_iter) that `rank` renders.
+    Iteration i (counted from 1, as the reference counts them) lies in block (i - 1) // block, and block b goes
+    to rank b % world: who renders an iteration depends on its number alone, not on how the caller cuts its
+    calls, so successive short calls (one iteration per Render, as the reference's frame loop makes them) rotate
+    over the ranks."""
     if block <= 0 or world <= 0 or not (0 <= rank < world):
         raise ValueError("bad sharding arguments")
     out = []
-    b = 0
     it = first_iter
     end = first_iter + n_iter
     while it < end:
-        n = min(block, end - it)
+        b = max(it - 1, 0) // block
+        block_end = min(end, (b + 1) * block + 1)
         if b % world == rank:
-            out.append((it, n))
-        it += n
-        b += 1
+            out.append((it, block_end - it))
+        it = block_end
     return out
 
 

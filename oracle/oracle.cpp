@@ -12,7 +12,9 @@
 // by the HIP renderer):
 //   * every `uniform(rng)` inside one expression is drawn left to right;
 //   * transcendental functions and rsqrt come from fpspec.h, fmin/fmax drop
-//     NaNs, there is no fused multiply-add;
+//     NaNs; dot and cross products are fused as nvcc's default contraction
+//     fuses them and the slab test is one fused multiply-add per plane
+//     (fpspec.h), nothing else is fused;
 //   * the Triangle shading frame is n = ns, dpdu = ss (Triangle.h:122-136 does
 //     not compile; cross(ss,ts) is parallel to ns so Faceforward returns ns);
 //   * a sphere hit whose chosen root lies beyond ray.tmax is rejected (the
@@ -84,9 +86,10 @@ inline V3& operator*=(V3& a, float s) { a = a * s; return a; }
 inline V3& operator/=(V3& a, float s) { a = a / s; return a; }
 inline V4 operator*(float s, V4 a) { return V4{s * a.x, s * a.y, s * a.z, s * a.w}; }
 inline V4 operator+(V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
-inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // cutil_math.h:1136
-inline V3 cross(V3 a, V3 b) {                                                // cutil_math.h:1308
-  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+// cutil_math.h:1136 and :1308, with the fused multiply-adds nvcc's default contraction puts there (fpspec.h)
+inline float dot(V3 a, V3 b) { return fps::dot3_(a.x, a.y, a.z, b.x, b.y, b.z); }
+inline V3 cross(V3 a, V3 b) {
+  return V3{fps::diffprod_(a.y, b.z, a.z, b.y), fps::diffprod_(a.z, b.x, a.x, b.z), fps::diffprod_(a.x, b.y, a.y, b.x)};
 }
 inline float length(V3 v) { return sqrtf(dot(v, v)); }                       // cutil_math.h:1179
 inline V3 normalize(V3 v) { return v * fps::rsqrt_(dot(v, v)); }             // cutil_math.h:1197
@@ -221,12 +224,15 @@ struct Counters {
 // The two distances of the slab test (bbox.h:76-87): where the ray enters and leaves the box.
 inline void SlabDistances(V3 lo, V3 hi, const Ray& r, float& tNear, float& tFar) {
   V3 inv = {1.f / r.dir.x, 1.f / r.dir.y, 1.f / r.dir.z};
-  float txNear = (lo.x - r.origin.x) * inv.x;
-  float txFar = (hi.x - r.origin.x) * inv.x;
-  float tyNear = (lo.y - r.origin.y) * inv.y;
-  float tyFar = (hi.y - r.origin.y) * inv.y;
-  float tzNear = (lo.z - r.origin.z) * inv.z;
-  float tzFar = (hi.z - r.origin.z) * inv.z;
+  // (plane - origin) * inv as one fused multiply-add per plane where the ray allows it (fpspec.h)
+  V3 noi = {-(r.origin.x * inv.x), -(r.origin.y * inv.y), -(r.origin.z * inv.z)};
+  const bool fused = fps::slab_fused_(noi.x, noi.y, noi.z);
+  float txNear = fps::slab_plane_(lo.x, r.origin.x, inv.x, noi.x, fused);
+  float txFar = fps::slab_plane_(hi.x, r.origin.x, inv.x, noi.x, fused);
+  float tyNear = fps::slab_plane_(lo.y, r.origin.y, inv.y, noi.y, fused);
+  float tyFar = fps::slab_plane_(hi.y, r.origin.y, inv.y, noi.y, fused);
+  float tzNear = fps::slab_plane_(lo.z, r.origin.z, inv.z, noi.z, fused);
+  float tzFar = fps::slab_plane_(hi.z, r.origin.z, inv.z, noi.z, fused);
   using fps::fmax_;
   using fps::fmin_;
   tNear = fmax_(fmax_(fmin_(txNear, txFar), fmin_(tyNear, tyFar)), fmin_(tzNear, tzFar));

