@@ -64,7 +64,7 @@ EXPORTS = [
     "caster_render", "caster_render_async", "caster_sync", "caster_read_film", "caster_read_film_device",
     "caster_film_add_device", "caster_primary_ids", "caster_trace_rays", "caster_trace_rays_static", "caster_eval_function", "caster_get_stats", "caster_get_walk_counts", "caster_reset_stats",
     "caster_iterations", "caster_end", "caster_last_error", "caster_set_profiling", "caster_get_kernel_times",
-    "caster_write_image", "caster_save_image", "caster_iters_in_flight",
+    "caster_write_image", "caster_save_image", "caster_iters_in_flight", "caster_checkpoint_save", "caster_checkpoint_load",
 ]
 
 
@@ -118,6 +118,8 @@ def lib():
         L.caster_film_add_device.argtypes = [vp, vp, C.c_uint32]
         L.caster_write_image.argtypes = [C.c_char_p, C.c_int, C.c_int, fp]
         L.caster_save_image.argtypes = [vp, C.c_char_p, C.c_int]
+        L.caster_checkpoint_save.argtypes = [vp, C.c_char_p]
+        L.caster_checkpoint_load.argtypes = [vp, C.c_char_p]
         L.caster_primary_ids.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32)]
         L.caster_trace_rays.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.POINTER(C.c_int32), C.POINTER(C.c_float)]
@@ -236,6 +238,16 @@ class Renderer:
     def save_image(self, path, mode=-1):
         """Writes the film as .png / .exr / .pfm (the reference's SaveImage, CudaRender.cpp:84-90)."""
         _check(lib().caster_save_image(self._h, os.fspath(path).encode(), mode))
+
+    def save_checkpoint(self, path):
+        """Writes the raw film sum and the iteration count (caster_checkpoint_save)."""
+        _check(lib().caster_checkpoint_save(self._h, os.fspath(path).encode()))
+
+    def load_checkpoint(self, path):
+        """Replaces film and iteration count with a checkpoint's; returns the iterations it holds, so that
+        ``render(n + 1, ...)`` continues the render."""
+        _check(lib().caster_checkpoint_load(self._h, os.fspath(path).encode()))
+        return self.iterations
 
     def primary_ids(self, it=1):
         ids = np.empty((self.height, self.width), np.int32)

@@ -540,23 +540,24 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
 
   const bool default_pool = iters_in_flight <= 0;
   if (default_pool) {
-    // late bounces keep few rays alive: a batch needs tens of millions of paths
-    // for their launches to fill the chip (the pools are sized for 288 GB of HBM:
-    // 128 M slots x 380 B per stream; 192 M slots -- 96 iterations of 1080p -- measured no faster: 1753
-    // against 1757 Msamples/s)
-    long long target = 128ll << 20;
+    // Late bounces keep few rays alive: a batch needs tens of millions of paths for their launches to fill the
+    // chip.  The default is 64 M path slots per stream (32 iterations of 1080p; 76 GB with three streams), which
+    // costs 1 % on the 1.37 M-triangle benchmark scene against twice that and nothing on the smaller scenes; a
+    // caller that wants the last percent states iters_in_flight (128 M slots x 380 B per stream = 150 GB; 192 M
+    // measured no faster), one that shares the card states less.
+    long long target = 64ll << 20;
     iters_in_flight = (int)std::max<long long>(1, std::min<long long>(64, target / S.slots_per_iter));
   }
   if (n_streams <= 0) n_streams = kDefaultStreams;
   if (n_streams > kMaxStreams) n_streams = kMaxStreams;
   if (default_pool) {
-    // the default pools take at most half of the memory that is free right now
-    // (other renderers or processes may share the GPU); a caller that states
-    // iters_in_flight gets what it asked for or an allocation error
+    // the default pools take at most a quarter of the memory that is free right now (a host that links this
+    // library may hold something of its own, and other renderers or processes may share the GPU); a caller
+    // that states iters_in_flight gets what it asked for or an allocation error
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
       const double per_iter = (double)S.slots_per_iter * kBytesPerSlot * n_streams;
-      long long fit = (long long)((double)free_b * 0.5 / per_iter);
+      long long fit = (long long)((double)free_b * 0.25 / per_iter);
       iters_in_flight = (int)std::max<long long>(1, std::min<long long>(iters_in_flight, fit));
     }
   }
@@ -1071,6 +1072,11 @@ int caster_render_async(caster_renderer* r, uint32_t first_iter, uint32_t n_iter
     HIPCHECK(hipStreamSynchronize(r->lanes[0].stream));
     r->iterations = 0;
   }
+  if (r->live_pixels == 0) {   // a renderer that owns no scanline (a device group larger than the image has slabs)
+    r->ahead_lane = -1;
+    r->iterations += n_iter;
+    return CASTER_OK;
+  }
   const uint32_t n_lanes = (uint32_t)r->lanes.size();
   // One iteration per call with a look-ahead window: the window's iterations are traced together the first
   // time one of them is asked for, and each call adds its own iteration to the film.
@@ -1236,6 +1242,86 @@ int caster_film_add_device(caster_renderer* r, const float* sum_device, uint32_t
   HIPCHECK(hipStreamSynchronize(st));
   r->iterations += n_iters;
   return CASTER_OK;
+}
+
+// ---- film checkpoint ------------------------------------------------------------------------------------------
+namespace caster {
+struct CheckpointHeader {
+  char magic[8];       // "CSTRFILM"
+  uint32_t version;    // 1
+  uint32_t width, height;
+  uint32_t iterations; // iterations the sum holds
+  int32_t integrator;
+  uint32_t reserved[3];
+};
+static const char kCheckpointMagic[8] = {'C', 'S', 'T', 'R', 'F', 'I', 'L', 'M'};
+}  // namespace caster
+
+int caster_checkpoint_save(caster_renderer* r, const char* path) {
+  if (!r || !path) return fail(CASTER_ERR_ARG, "caster_checkpoint_save: null argument");
+  const size_t n = (size_t)r->S.width * r->S.height * 3;
+  std::vector<float> host(n);
+  int rc = caster_read_film(r, host.data(), 2);
+  if (rc) return rc;
+  CheckpointHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, kCheckpointMagic, 8);
+  h.version = 1; h.width = (uint32_t)r->S.width; h.height = (uint32_t)r->S.height;
+  h.iterations = r->iterations; h.integrator = r->S.integrator;
+  // written beside the target and renamed over it: a reader never sees half a checkpoint
+  const std::string tmp = std::string(path) + ".part";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return fail(CASTER_ERR_ARG, "caster_checkpoint_save: cannot write " + tmp);
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(host.data(), sizeof(float), n, f) == n;
+  ok = (fclose(f) == 0) && ok;
+  if (!ok || rename(tmp.c_str(), path) != 0) {
+    remove(tmp.c_str());
+    return fail(CASTER_ERR_ARG, std::string("caster_checkpoint_save: writing ") + path + " failed");
+  }
+  return CASTER_OK;
+}
+
+int caster_checkpoint_load(caster_renderer* r, const char* path) {
+  if (!r || !path) return fail(CASTER_ERR_ARG, "caster_checkpoint_load: null argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(CASTER_ERR_ARG, std::string("caster_checkpoint_load: cannot read ") + path);
+  CheckpointHeader h;
+  const size_t n = (size_t)r->S.width * r->S.height * 3;
+  std::vector<float> host(n);
+  bool ok = fread(&h, sizeof(h), 1, f) == 1;
+  const bool ours = ok && memcmp(h.magic, kCheckpointMagic, 8) == 0 && h.version == 1;
+  const bool fits = ours && h.width == (uint32_t)r->S.width && h.height == (uint32_t)r->S.height && h.integrator == r->S.integrator;
+  if (fits) ok = fread(host.data(), sizeof(float), n, f) == n && fgetc(f) == EOF;
+  fclose(f);
+  if (!ours) return fail(CASTER_ERR_ARG, std::string("caster_checkpoint_load: ") + path + " is not a film checkpoint");
+  if (!fits) return fail(CASTER_ERR_ARG, std::string("caster_checkpoint_load: ") + path + " was written for another image size or integrator");
+  if (!ok) return fail(CASTER_ERR_ARG, std::string("caster_checkpoint_load: ") + path + " is truncated or holds trailing bytes");
+  // an empty film (whatever was traced ahead is dropped with it), then the stored sum and its iteration count
+  int rc = caster_render(r, 1, 0, 1);
+  if (rc) return rc;
+  if (!r->parts.empty() && r->shard_mode == CASTER_SHARD_TILE) {
+    // Every part of a group that deals scanlines gets the stored sum of ITS scanlines: a part's film then goes on
+    // exactly as it would have without the interruption, and the gathered film is the uninterrupted one bit for bit.
+    const size_t row = (size_t)r->S.width * 3;
+    for (caster_renderer* p : r->parts) {
+      std::vector<float> mine(n, 0.f);
+      const DevScene& S = p->S;
+      for (int y = 0; y < S.height; ++y)
+        if (y >= S.row_y0 && y < S.row_y1 && (y - S.row_y0) % S.row_stride < S.row_rows)
+          memcpy(&mine[(size_t)y * row], &host[(size_t)y * row], row * sizeof(float));
+      HIPCHECK(hipSetDevice(p->device));
+      HIPCHECK(hipMemcpy(p->film_tmp, mine.data(), n * sizeof(float), hipMemcpyHostToDevice));
+      rc = caster_film_add_device(p, p->film_tmp, h.iterations);
+      if (rc) return rc;
+    }
+    r->iterations += h.iterations;
+    return CASTER_OK;
+  }
+  caster_renderer* p0 = r->parts.empty() ? r : r->parts[0];
+  float* stage = r->parts.empty() ? r->film_tmp : r->group_peer;
+  HIPCHECK(hipSetDevice(p0->device));
+  HIPCHECK(hipMemcpy(stage, host.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  return caster_film_add_device(r, stage, h.iterations);
 }
 
 int caster_primary_ids(caster_renderer* r, uint32_t iter, int32_t* ids) {
@@ -1547,7 +1633,18 @@ int caster_begin_multi(const caster_scene* s, const int* device_ids, int n_dev, 
   caster_renderer* g = new caster_renderer();
   g->shard_mode = shard_mode;
   g->parts.assign((size_t)n_dev, nullptr);
-  int rc = for_each_part(g, [&](int i) { return caster_begin_streams(s, device_ids[i], iters_in_flight, n_streams, &g->parts[(size_t)i]); });
+  // (CASTER_MULTI_ITERS="4,2,..." in the environment gives the parts these iterations in flight instead: a test
+  // knob that stands in for devices with different amounts of free memory)
+  std::vector<int> part_iters((size_t)n_dev, iters_in_flight);
+  if (const char* e = getenv("CASTER_MULTI_ITERS")) {
+    size_t k = 0;
+    for (const char* p = e; *p && k < part_iters.size(); ++k) {
+      part_iters[k] = atoi(p);
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
+  int rc = for_each_part(g, [&](int i) { return caster_begin_streams(s, device_ids[i], part_iters[(size_t)i], n_streams, &g->parts[(size_t)i]); });
   if (!rc && shard_mode == CASTER_SHARD_TILE) {
     // slabs of 8 scanlines dealt round-robin: part k of G traces the scanlines y >= 8k with (y - 8k) % 8G < 8
     const int h = s->scene.height;

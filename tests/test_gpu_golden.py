@@ -362,6 +362,162 @@ def test_several_devices_behind_one_handle(caster, key):
     assert rel_rmse(got, want) <= 1e-5
 
 
+def test_device_group_of_eight(caster, tmp_path):
+    """caster_begin_multi with EIGHT entries (all on the one GPU of the test box: eight host threads, eight
+    renderers, seven film copies and adds): both shard modes against one device, statistics of the whole job, and
+    the parity hooks -- caster_trace_rays and the entry point that allocates nothing -- through the group handle."""
+    import torch
+    sc = caster.Scene(os.path.join(GOLD, "scenes", "stairs_pt", "scene.json"))
+    spp = 19
+    one = caster.Renderer(sc, 0, 2)
+    one.render(1, spp, True)
+    want = one.read_film(2)
+    st1 = one.stats()
+    rng = np.random.default_rng(3)
+    n = 5000
+    o = rng.uniform(-2.0, 2.0, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = np.full(n, np.inf, np.float32)
+    want_prim, want_t = one.trace_rays(o, d, tmax)
+    one.close()
+    for shard in ("tile", "spp"):
+        g = caster.Renderer(sc, [0] * 8, 2, 1, shard=shard)
+        g.render(1, spp, True)
+        got = g.read_film(2)
+        st = g.stats()
+        assert g.iterations == spp and st["samples"] == st1["samples"] and st["rays"][0] == st1["rays"][0] and st["stack_overflow"] == 0
+        if shard == "tile":
+            np.testing.assert_array_equal(got, want)
+        else:
+            assert rel_rmse(got, want) <= 1e-5
+        prim, t = g.trace_rays(o, d, tmax)
+        np.testing.assert_array_equal(prim, want_prim)
+        np.testing.assert_array_equal(t.view(np.uint32), want_t.view(np.uint32))
+        dev = torch.device("cuda", 0)
+        to, td, tt = (torch.from_numpy(a).to(dev) for a in (o, d, tmax))
+        dprim = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        dt = torch.full((n,), -7.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        g.trace_rays_static(n, to.data_ptr(), td.data_ptr(), tt.data_ptr(), dprim.data_ptr(), dt.data_ptr())
+        np.testing.assert_array_equal(dprim.cpu().numpy(), want_prim)
+        np.testing.assert_array_equal(dt.cpu().numpy().view(np.uint32), want_t.view(np.uint32))
+        g.close()
+
+
+def test_device_group_whose_parts_hold_different_batches(caster, monkeypatch):
+    """Iteration sharding over parts whose pools differ (devices with different amounts of free memory; here the
+    test knob CASTER_MULTI_ITERS): the group cuts the iterations into blocks of ONE size, so every iteration is
+    rendered exactly once -- the sample and extension-ray counts are those of one device and the film is its film
+    up to the order of the additions.  Calls of one iteration each rotate over the parts."""
+    sc = caster.Scene(os.path.join(GOLD, "scenes", "cornell_pt", "scene.json"))
+    spp = 23
+    one = caster.Renderer(sc, 0, 4)
+    one.render(1, spp, True)
+    want = one.read_film(2)
+    st1 = one.stats()
+    one.close()
+    monkeypatch.setenv("CASTER_MULTI_ITERS", "8,2,4")
+    g = caster.Renderer(sc, [0, 0, 0], 0, 1, shard="spp")
+    monkeypatch.delenv("CASTER_MULTI_ITERS")
+    g.render(1, spp, True)
+    st = g.stats()
+    assert g.iterations == spp and st["samples"] == st1["samples"] and st["rays"][0] == st1["rays"][0]
+    assert rel_rmse(g.read_film(2), want) <= 1e-5
+    # the same iterations asked for one call at a time, the way the reference's frame loop asks
+    g.reset_stats()
+    for it in range(1, spp + 1):
+        g.render(it, 1, it == 1)
+    st = g.stats()
+    assert g.iterations == spp and st["samples"] == st1["samples"] and st["rays"][0] == st1["rays"][0]
+    assert rel_rmse(g.read_film(2), want) <= 1e-5
+    g.close()
+
+
+@pytest.mark.parametrize("key", ["stairs_pt", "cornell_fog_lt"])
+def test_checkpoint_and_resume(caster, tmp_path, key):
+    """caster_checkpoint_save / caster_checkpoint_load: 8 iterations, a checkpoint, a NEW renderer that loads it and
+    renders 8 more equal 16 iterations in one go bit for bit (a light-traced film, which is splatted with float
+    atomics, to the tolerance of that integrator); a file of another size is refused; so is a file that is not one."""
+    scene = os.path.join(GOLD, "scenes", key, "scene.json")
+    sc = caster.Scene(scene)
+    whole = caster.Renderer(sc, 0, 4)
+    whole.render(1, 16, True)
+    want = whole.read_film(2)
+    whole.close()
+    a = caster.Renderer(sc, 0, 4)
+    a.render(1, 8, True)
+    ck = str(tmp_path / "film.ckpt")
+    a.save_checkpoint(ck)
+    a.close()
+    assert not os.path.exists(ck + ".part")
+    b = caster.Renderer(sc, 0, 2, 2)
+    b.render(1, 3, True)                      # whatever the renderer held is replaced
+    assert b.load_checkpoint(ck) == 8
+    b.render(9, 8, False)
+    got = b.read_film(2)
+    assert b.iterations == 16
+    if sc.integrator in (3, 4):
+        assert rel_rmse(got, want) <= 1e-5
+    else:
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(b.read_film(1), caster_tonemapped(caster, sc, 16))
+    # through a device group
+    g = caster.Renderer(sc, [0, 0], 2, 1, shard="tile")
+    assert g.load_checkpoint(ck) == 8
+    g.render(9, 8, False)
+    if sc.integrator in (3, 4):
+        assert rel_rmse(g.read_film(2), want) <= 1e-5
+    else:
+        np.testing.assert_array_equal(g.read_film(2), want)
+    g.close()
+    other = caster.Scene(os.path.join(GOLD, "scenes", "cornell_pt", "scene.json"))
+    c = caster.Renderer(other, 0, 2)
+    with pytest.raises(caster.CasterError) as e:
+        c.load_checkpoint(ck)
+    assert e.value.code == 1 and "another image size" in str(e.value)
+    junk = str(tmp_path / "junk.ckpt")
+    open(junk, "wb").write(b"PF\n64 64\n-1.0\n" + bytes(64))
+    with pytest.raises(caster.CasterError) as e:
+        c.load_checkpoint(junk)
+    assert "not a film checkpoint" in str(e.value)
+    short = str(tmp_path / "short.ckpt")
+    open(short, "wb").write(open(ck, "rb").read()[:-5])
+    with pytest.raises(caster.CasterError) as e:
+        b.load_checkpoint(short)
+    assert "truncated" in str(e.value)
+    b.close()
+    c.close()
+
+
+def caster_tonemapped(caster, sc, n):
+    r = caster.Renderer(sc, 0, 4)
+    r.render(1, n, True)
+    img = r.read_film(1)
+    r.close()
+    return img
+
+
+def test_render_tool_resumes_from_a_checkpoint(tmp_path):
+    """tools/render.py --checkpoint / --resume: 6 iterations with a checkpoint, then 5 more resumed from it, write the
+    image of 11 iterations rendered in one go."""
+    import subprocess
+    import sys
+    scene = os.path.join(GOLD, "scenes", sorted(VEC["scenes"])[0], "scene.json")
+    tool = os.path.join(ROOT, "tools", "render.py")
+    ck = str(tmp_path / "film.ckpt")
+    runs = (("whole", ["--spp", "11"]), ("first", ["--spp", "6", "--checkpoint", ck]),
+            ("second", ["--spp", "5", "--resume", ck, "--checkpoint", ck]))
+    outs = {}
+    for name, extra in runs:
+        outs[name] = str(tmp_path / (name + ".pfm"))
+        p = subprocess.run([sys.executable, tool, scene, "--iters-in-flight", "2", "--out", outs[name]] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+    assert "on top of 6 resumed" in p.stdout
+    np.testing.assert_array_equal(_read_pfm(outs["second"]), _read_pfm(outs["whole"]))
+
+
 @pytest.mark.parametrize("key", ["cornell_ao", "stairs_pt", "cornell_vpt"])
 def test_one_iteration_calls_with_a_lookahead_window(caster, key):
     """caster_set_lookahead: calls for one iteration each trace a window of iterations together and add them to the

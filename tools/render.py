@@ -10,6 +10,11 @@ One process per GPU.  With several ranks the iterations (``--shard spp``) or ban
 rank 0 in one RCCL reduce, which then writes the image: .png is tonemapped as the reference's
 Output() + SavePng do, .exr and .pfm hold the linear mean.
 
+``--checkpoint FILE`` keeps the raw film sum and the iteration count in FILE (rewritten whenever the image is),
+``--resume FILE`` continues from such a file: iterations n + 1 .. n + spp are rendered on top of the n it holds, and
+the result equals n + spp iterations rendered in one go (a sample depends on its pixel and iteration alone, and the
+film is a sum).
+
 ``--preview-every K`` rewrites the image after every K samples per pixel (the reference's window
 shows its running mean after every iteration, CudaRender.cpp:48-60): the ranks' films are reduced
 at each of those points, rank 0 keeps the running sum and the other ranks start their film afresh.
@@ -33,6 +38,8 @@ def main():
     ap.add_argument("--gpu-bvh", action="store_true", help="build the BVH on the GPU (same tree as the host build)")
     ap.add_argument("--iters-in-flight", type=int, default=0)
     ap.add_argument("--preview-every", type=int, default=0, metavar="K", help="rewrite the image after every K samples per pixel")
+    ap.add_argument("--checkpoint", default=None, metavar="FILE", help="write the raw film sum + iteration count here whenever the image is written")
+    ap.add_argument("--resume", default=None, metavar="FILE", help="continue from a checkpoint: --spp more iterations on top of those it holds")
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo + --share-gpu rehearses N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses device 0 (rehearsal only)")
     a = ap.parse_args()
@@ -52,6 +59,13 @@ def main():
             dist.init_process_group(a.backend)
     scene = caster.Scene(a.scene, build_device=dev if a.gpu_bvh else None)
     r = caster.Renderer(scene, dev, a.iters_in_flight)
+    base = 0              # iterations rendered before this run (their sum sits in rank 0's film)
+    if a.resume:
+        import struct
+        with open(a.resume, "rb") as f:
+            magic, version, cw, ch, base, cinteg = struct.unpack("<8sIIIIi", f.read(28))
+        if rank == 0:
+            r.load_checkpoint(a.resume)   # (checks magic, size and integrator)
     t0 = time.perf_counter()
     tonemapped = a.out.lower().endswith(".png")
     if world > 1:
@@ -64,14 +78,14 @@ def main():
     # samples per pixel between two images: all of them unless previews are asked for
     step = a.spp if a.preview_every <= 0 else min(a.preview_every, a.spp)
     done = 0
-    fresh = True          # this rank's film holds nothing yet
+    fresh = not (a.resume and rank == 0)   # this rank's film holds nothing yet
     while done < a.spp:
         n_round = min(step, a.spp - done)
         if world > 1 and a.shard == "tile":
-            blocks = [(1 + done, n_round)]
+            blocks = [(1 + base + done, n_round)]
         else:
             block = max(1, min(64, n_round // max(world, 1)))
-            blocks = sharding.spp_blocks(1 + done, n_round, block, rank, world)
+            blocks = sharding.spp_blocks(1 + base + done, n_round, block, rank, world)
         for it, n in blocks:
             r.render_async(it, n, fresh)
             fresh = False
@@ -79,6 +93,8 @@ def main():
         done += n_round
         if world == 1:
             r.save_image(a.out)
+            if a.checkpoint:
+                r.save_checkpoint(a.checkpoint)
         else:
             # the library works on its own streams, torch on another: meet on the host in between
             if fresh:
@@ -97,16 +113,19 @@ def main():
                 # the summed film (rank 0's own included) back into the renderer, which divides,
                 # tonemaps and writes it, and keeps adding to it in the next round
                 r.render(1, 0, True)
-                r.film_add_device(film.data_ptr(), done)
+                r.film_add_device(film.data_ptr(), base + done)
                 r.save_image(a.out)
+                if a.checkpoint:
+                    r.save_checkpoint(a.checkpoint)
             else:
                 fresh = True   # handed over: the next round starts from an empty film
         if rank == 0 and done < a.spp:
             print("preview: %d of %d spp after %.2f s -> %s" % (done, a.spp, time.perf_counter() - t0, a.out), flush=True)
     if rank == 0:
         dt = time.perf_counter() - t0
-        print("%s: %dx%d, %d spp on %d GPU(s) in %.2f s (%.1f Msamples/s) -> %s%s" % (
-            caster.INTEGRATOR_NAMES[scene.integrator], scene.width, scene.height, a.spp, world, dt,
+        print("%s: %dx%d, %d spp%s on %d GPU(s) in %.2f s (%.1f Msamples/s) -> %s%s" % (
+            caster.INTEGRATOR_NAMES[scene.integrator], scene.width, scene.height, a.spp,
+            " on top of %d resumed" % base if base else "", world, dt,
             scene.width * scene.height * a.spp / dt / 1e6, a.out, " (tonemapped)" if tonemapped else ""))
     r.close()
     if dist is not None:
