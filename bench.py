@@ -14,12 +14,15 @@ are summed onto rank 0 with one RCCL reduce inside the timed region.
 Started without a launcher, `--gpus N` starts its own N ranks (torch.distributed.run as a child process,
 before anything here touches a GPU) and passes rank 0's line on.
 
-Rank 0 prints one JSON line.  `roofline` prices the kernel that takes most of the GPU's time with
-the bytes it itself requests (GPU-side counters: 112 B per 4-wide node record fetched + 48 B per primitive
-record tested + the ray and hit records moved) at the duration of a launch that has the GPU to itself,
-against the roof that applies (L2 bandwidth for the traversal's record gathers, HBM for the shade stage),
-next to the HBM-side traffic of the committed PMC passes and to what the reference's own traversal order
-would have requested (`work_avoided`; visit counts of the CPU oracle on a sample of the same workload).
+Rank 0 prints one JSON line.  `roofline` holds the kernel that takes most of the GPU's time against the roof
+that binds it: for the traversal kernel that is vector-instruction issue (instructions per launch from the
+committed PMC passes over the launch duration measured in this run, against one wave64 instruction per SIMD
+per four clocks; the clock is sampled in this run).  Beside it, as `bytes`, the bytes the kernel itself requests
+(GPU-side counters: 112 B per 4-wide node record fetched + 48 B per primitive record tested + the ray and hit
+records moved) over the same duration against L2 bandwidth, the L2-side and HBM-side bytes of the PMC passes,
+and what the reference's own traversal order would have requested (`work_avoided`; visit counts of the CPU
+oracle on a sample of the same workload).  Every number that comes from the committed PMC file rather than
+from this run says so (`source`).
 `cpu_baseline` is that oracle (a transcription of the reference integrators; the reference itself does not
 compile) timed on this host's cores.
 """
@@ -79,59 +82,88 @@ def algorithmic_bytes_per_ray(counts, kind):
             + 32.0 * counts["lines"][kind]) / rays
 
 
-def pmc_traffic_per_launch(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/r02_pmc.json: per-dispatch averages of FETCH_SIZE and WRITE_SIZE, in KiB).
-    FETCH_SIZE counts half the bytes on gfx950, for 16-byte-per-lane streaming reads and for the
-    128-byte record gathers of the traversal alike (tools/calib/fetch_calib.hip measures both
-    against known byte counts), so it is doubled; WRITE_SIZE is exact.  None without the file."""
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")
+PMC_SOURCE = ("committed PMC pass: %s, per-dispatch averages of rocprofv3 --pmc runs of this same command on the builder's "
+              "own lease (tools/gpu_prof.sh); not measured in this run" % PMC_FILE)
+TCP_REQ_BYTES = 128.0   # bytes per L1 -> L2 read request, calibrated with known byte counts (profiles/r03_calib_tcp.txt)
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9
+VALU_PEAK_PER_S = N_SIMD * PEAK_CLOCK_HZ / 4.0   # wave64 vector instructions per second: one per SIMD per four clocks
+
+
+def load_pmc():
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
-            k = json.load(f)[kernel]
-        return (2.0 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
 
 
-def pmc_secondary(kernel, n_simd=1024):
-    """What else the committed PMC passes say about `kernel` (per-dispatch averages): the share of the time its
-    SIMDs' vector ALUs were issuing (SQ_ACTIVE_INST_VALU over the wavefronts' lifetime per SIMD; the SQ counts in
-    units of four clocks, one wave64 instruction each), the lanes active in an issued vector instruction, the L2
-    hit rate and the wavefronts resident per SIMD.  None without the file."""
+def pmc_of(pmc, kernel):
+    """What the committed PMC passes say about `kernel`, per launch (per-dispatch averages), every number labelled
+    with its source.  hbm_bytes: FETCH_SIZE counts half the bytes on gfx950, for 16-byte-per-lane streaming reads and
+    for the 128-byte record gathers of the traversal alike (tools/calib/fetch_calib.hip measures both against known
+    byte counts), so it is doubled; WRITE_SIZE is exact; both are in KiB.  l2_request_bytes: L1 -> L2 read requests x
+    128 B (calibrated the same way).  valu_issue_busy: SQ_ACTIVE_INST_VALU over the wavefronts' lifetime per SIMD (the
+    SQ counts in units of four clocks, one wave64 instruction each).  None without the file or the kernel."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
-            k = json.load(f)[kernel]
-        waves_per_simd = k["SQ_WAVES"]["avg"] / n_simd
-        return {"valu_issue_busy": k["SQ_ACTIVE_INST_VALU"]["avg"] / (k["SQ_WAVE_CYCLES"]["avg"] / waves_per_simd) ,
-                "valu_lane_utilisation": k["SQ_THREAD_CYCLES_VALU"]["avg"] / (64.0 * k["SQ_ACTIVE_INST_VALU"]["avg"]),
+        k = pmc[kernel]
+        waves_per_simd = k["SQ_WAVES"]["avg"] / N_SIMD
+        return {"source": PMC_SOURCE,
+                "valu_wave_instructions": k["SQ_INSTS_VALU"]["avg"],
+                "valu_issue_busy": k["SQ_ACTIVE_INST_VALU"]["avg"] / (k["SQ_WAVE_CYCLES"]["avg"] / waves_per_simd),
+                "useful_lane_frac": k["SQ_THREAD_CYCLES_VALU"]["avg"] / (64.0 * k["SQ_ACTIVE_INST_VALU"]["avg"]),
                 "l2_hit_rate": k["TCC_HIT_sum"]["avg"] / (k["TCC_HIT_sum"]["avg"] + k["TCC_MISS_sum"]["avg"]),
-                "waves_per_simd": waves_per_simd}
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
+                "waves_per_simd": waves_per_simd,
+                "hbm_bytes": (2.0 * k["FETCH_SIZE"]["avg"] + k["WRITE_SIZE"]["avg"]) * 1024.0,
+                "l2_request_bytes": k["TCP_TCC_READ_REQ_sum"]["avg"] * TCP_REQ_BYTES}
+    except (TypeError, KeyError, ValueError, ZeroDivisionError):
         return None
 
 
-VALU_PEAK_PER_S = 1024 * 2.4e9 / 4.0   # wave64 vector instructions per second: 256 CUs x 4 SIMDs, one per four clocks, 2.4 GHz
+class ClockSampler:
+    """Samples the shader clock the driver reports for this device (the starred level of pp_dpm_sclk) every 20 ms
+    while the timed region runs: the chip does not hold its 2.4 GHz peak under this load."""
 
+    def __init__(self, index):
+        import glob
+        import threading
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = cards[index] if index < len(cards) else None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
 
-def valu_issue(kernel_launches, shade_name, steps, dt):
-    """The share of the chip's vector-instruction issue the timed region used: wave64 vector instructions per launch of
-    every kernel from the committed PMC passes of this same command (SQ_INSTS_VALU, profiles/r02_pmc.json) x the launches
-    of the timed region, over what 1024 SIMDs issue at one instruction per four clocks and the 2.4 GHz peak clock.  (The
-    chip holds about 2.0 GHz under this load, so the fraction of the issue slots there actually were is a fifth higher.)
-    None without the file, or for a command other than the profiled one (other kernels)."""
-    symbols = {"generate": "k_generate", "extend": "k_trace<false>", "shadow": "k_trace<true>", "shade": shade_name,
-               "finish": "k_finish"}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
-            pmc = json.load(f)
-        total = sum(pmc[sym]["SQ_INSTS_VALU"]["avg"] * kernel_launches.get(cat, 0) for cat, sym in symbols.items())
-    except (OSError, KeyError, ValueError):
+    def _read(self):
+        try:
+            with open(self.path) as f:
+                for line in f:
+                    if "*" in line:
+                        return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
         return None
-    if kernel_launches.get("probe", 0) or dt <= 0:
-        return None
-    return {"bound": "valu", "wave_instructions_per_step": total / max(steps, 1), "achieved": total / dt / 1e9,
-            "peak": VALU_PEAK_PER_S / 1e9, "unit": "G wave64 vector instructions/s", "frac": total / dt / VALU_PEAK_PER_S,
-            "note": "all kernels of the timed region together; per-launch instruction counts of the committed PMC passes"}
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v is not None:
+                self.samples.append(v)
+            self._stop.wait(0.02)
+
+    def start(self):
+        if self.path:
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self.path:
+            self._thread.join()
+        if not self.samples:
+            return None
+        xs = sorted(self.samples)
+        return {"mean": sum(xs) / len(xs), "min": xs[0], "median": xs[len(xs) // 2], "max": xs[-1], "samples": len(xs),
+                "source": "measured in this run: %s sampled every 20 ms over the timed region" % self.path}
 
 
 def launch_ranks(n, argv):
@@ -204,7 +236,14 @@ def main():
     path = scene_path(a.scene, a.detail, a.width, a.height, a.depth, rank, barrier, a.integrator)
     scene = caster.Scene(path)
     sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
-    r = caster.Renderer(scene, dev_index, a.iters_in_flight, a.streams)
+    # The library's default pools are sized for a host that shares the card (64 M paths per stream, a quarter of the
+    # free memory at most); a benchmark rank has its GPU to itself and asks for the 128 M paths per stream that are
+    # the last percent faster -- unless the ranks share one card (rehearsals).
+    iters = a.iters_in_flight
+    if iters <= 0 and not a.share_gpu:
+        slots = ((scene.width + 7) // 8) * ((scene.height + 7) // 8) * 64
+        iters = max(1, min(64, (128 << 20) // slots))
+    r = caster.Renderer(scene, dev_index, iters, a.streams)
     r_streams = a.streams or 3
     spp = a.spp_per_step or r_streams * r.iters_in_flight
     npix = scene.width * scene.height
@@ -231,8 +270,10 @@ def main():
     r.render(1, 0, True)          # clear the film and the iteration count
     r.set_profiling(True)
 
+    clock = ClockSampler(dev_index)
     barrier()
     torch.cuda.synchronize()
+    clock.start()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         r.render_async(first_iter(step_no), spp, False)
@@ -247,6 +288,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    sclk = clock.stop()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,6 +304,15 @@ def main():
     rays = [float(x) for x in rays]
     total_samples = rays[4]
     total_rays = sum(rays[:4])
+    # what the process group really is: backend, size, and every rank's device, gathered onto rank 0
+    group = None
+    if world > 1:
+        mine = {"rank": rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index),
+                "samples": st["samples"], "seconds": time.perf_counter() - t0}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        group = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
+                 "film_reduce": "torch.distributed.reduce(sum) of %d floats onto rank 0, inside the timed region" % (npix * 3)}
 
     if rank == 0:
         out = {
@@ -295,8 +346,14 @@ def main():
                              "tile (slabs of 8 scanlines dealt round-robin over the ranks, one film reduce)"),
             },
             "kernel_ms": {k: v[0] for k, v in kt.items()},
+            "kernel_ms_note": "OVERLAPPED: launch durations summed over %d streams that share the GPU, so the classes add up to more "
+                              "than steps x ms_per_step; durations of launches that have the GPU to themselves are under "
+                              "roofline.exclusive" % r_streams,
             "kernel_launches": {k: v[1] for k, v in kt.items()},
+            "sclk_mhz": sclk,
         }
+        if group is not None:
+            out["process_group"] = group
         counts = None
         if not a.no_cpu and world == 1:   # (the CPU baseline belongs to the one-GPU line)
             import oracle_lib as ol
@@ -397,24 +454,75 @@ def main():
             record = {"extend": 32 + 16, "shadow": 32 + 4, "probe": 32 + 4 + 16}
             return sum(rays_now[kind] * (algorithmic_bytes_per_ray(counts, kind) + record[c]) for c, kind in symbols[sym])
 
+        pmc = load_pmc() if a.scene == "car_pt" and (scene.width, scene.height) == (1920, 1080) else None   # (the profiled command)
+        sclk_hz = sclk["mean"] * 1e6 if sclk else None
+
         def roofline_of(sym, times, rays_now, walk_now, samples_now):
+            """One kernel against its roofs.  Measured in this run: launch durations (HIP events on the renderer's own
+            streams), the bytes the kernel requests (its own counters), the clock.  From the committed PMC passes, and
+            labelled so (`pmc.source`): vector instructions per launch, lane utilisation, HBM-side and L2-side bytes."""
             ms = sum(times[c][0] for c, _ in symbols[sym])
             launches = sum(times[c][1] for c, _ in symbols[sym])
             req = requested_bytes(sym, rays_now, walk_now, samples_now)
-            bound, peak = ROOF[sym]
-            r = {"kernel": sym, "bound": bound, "peak": peak, "unit": "GB/s", "total_ms": ms, "launches": launches,
-                 "avg_launch_ms": ms / max(launches, 1), "requested_bytes_per_launch": req / max(launches, 1)}
-            r["achieved"] = req / (ms * 1e-3) / 1e9 if ms > 0 and req > 0 else None
-            r["frac"] = r["achieved"] / peak if r["achieved"] is not None else None
+            level, peak = ROOF[sym]
+            per_launch_s = ms * 1e-3 / max(launches, 1)
+            r = {"kernel": sym, "total_ms": ms, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+                 "requested_bytes_per_launch": req / max(launches, 1)}
+            by = {"bound": level, "peak": peak, "unit": "GB/s",
+                  "achieved": req / (ms * 1e-3) / 1e9 if ms > 0 and req > 0 else None,
+                  "what": "bytes the kernel's loads and stores request (its own counters, this run) over the launch duration "
+                          "(this run), against the memory level that serves most of them; the per-CU cache serves most of "
+                          "the traversal's requests, so this prices L1-served bytes against the L2 roof -- see l2_side"}
+            by["frac"] = by["achieved"] / peak if by["achieved"] is not None else None
             ref = reference_walk_bytes(sym, rays_now)
-            r["work_avoided"] = ref / req if ref and req else None
-            r["traffic"] = pmc_traffic_per_launch(sym)
-            if r["traffic"] is not None and ms > 0 and req > 0:
+            by["work_avoided"] = ref / req if ref and req else None
+            k = pmc_of(pmc, sym)
+            if k is not None and per_launch_s > 0:
                 # (the PMC passes ran the same command: launches of the same average size)
-                r["traffic_over_requested"] = r["traffic"] / r["requested_bytes_per_launch"]
-                r["hbm_frac"] = r["traffic"] * launches / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            r["pmc"] = pmc_secondary(sym)
+                k["valu_issue"] = {"achieved": k["valu_wave_instructions"] / per_launch_s / 1e9, "peak": VALU_PEAK_PER_S / 1e9,
+                                   "unit": "G wave64 vector instructions/s",
+                                   "frac": k["valu_wave_instructions"] / per_launch_s / VALU_PEAK_PER_S,
+                                   "frac_at_measured_clock": (k["valu_wave_instructions"] / per_launch_s / (N_SIMD * sclk_hz / 4.0)
+                                                              if sclk_hz else None),
+                                   "what": "instructions per launch (PMC pass) over this run's launch duration, against one "
+                                           "wave64 instruction per SIMD per four clocks at the 2.4 GHz peak clock / at the "
+                                           "clock sampled in this run"}
+                k["hbm_side"] = {"bytes_per_launch": k["hbm_bytes"], "over_requested": k["hbm_bytes"] / r["requested_bytes_per_launch"] if req > 0 else None,
+                                 "achieved": k["hbm_bytes"] / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": k["hbm_bytes"] / per_launch_s / 1e9 / HBM_PEAK_GBS}
+                k["l2_side"] = {"bytes_per_launch": k["l2_request_bytes"], "achieved": k["l2_request_bytes"] / per_launch_s / 1e9,
+                                "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": k["l2_request_bytes"] / per_launch_s / 1e9 / L2_PEAK_GBS,
+                                "what": "L1 -> L2 read requests x 128 B (calibrated, profiles/r03_calib_tcp.txt) over this run's launch duration"}
+            r["bytes"] = by
+            r["pmc"] = k
             return r
+
+        def top_level(dom):
+            """The `roofline` object of the line: the dominant kernel against the roof that binds it.  For the traversal
+            kernel that is vector-instruction issue (its SIMDs' vector ALUs issue for most of the launch while its
+            records come from the caches); without the PMC file, or for a streaming kernel, the byte roof."""
+            k = dom.get("pmc")
+            t = {"kernel": dom["kernel"], "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
+                 "requested_bytes_per_launch": dom["requested_bytes_per_launch"]}
+            if k is not None and dom["kernel"].startswith("k_trace"):
+                t.update({"bound": "valu_issue", "achieved": k["valu_issue"]["achieved"], "peak": k["valu_issue"]["peak"],
+                          "unit": k["valu_issue"]["unit"], "frac": k["valu_issue"]["frac"],
+                          "frac_at_measured_clock": k["valu_issue"]["frac_at_measured_clock"],
+                          "useful_lane_frac": k["useful_lane_frac"], "traffic": k["hbm_bytes"],
+                          "measured_in_this_run": ["avg_launch_ms", "launches", "requested_bytes_per_launch", "sclk_mhz", "bytes.achieved"],
+                          "from_committed_pmc_pass": {"source": PMC_SOURCE,
+                                                      "fields": ["achieved (instructions per launch)", "frac", "useful_lane_frac", "traffic",
+                                                                 "bytes.hbm_side", "bytes.l2_side"]},
+                          "note": "the kernel's SIMDs issue vector instructions for frac of the launch at the peak clock "
+                                  "(frac_at_measured_clock at the clock the chip held), with useful_lane_frac of each "
+                                  "instruction's lanes active; its bytes are secondary (`bytes`)"})
+                t["bytes"] = dict(dom["bytes"], hbm_side=k["hbm_side"], l2_side=k["l2_side"])
+            else:
+                t.update({"bound": dom["bytes"]["bound"], "achieved": dom["bytes"]["achieved"], "peak": dom["bytes"]["peak"],
+                          "unit": "GB/s", "frac": dom["bytes"]["frac"], "traffic": k["hbm_bytes"] if k else None,
+                          "measured_in_this_run": ["avg_launch_ms", "launches", "requested_bytes_per_launch", "achieved", "frac"],
+                          "from_committed_pmc_pass": {"source": PMC_SOURCE, "fields": ["traffic"]} if k else None})
+            return t
 
         walk = r.walk_counts()
         iters_in_flight = r.iters_in_flight
@@ -422,17 +530,24 @@ def main():
         per_kernel = [roofline_of(sym, kt, st["rays"], walk, st["samples"]) for sym in symbols]
         # every launch of the timed region against the wall time: what the three kernels together asked for per second
         pipeline_req = sum(k["requested_bytes_per_launch"] * k["launches"] for k in per_kernel)
-        roof = {"valu_issue": valu_issue(out["kernel_launches"], shade_name, a.steps, dt) if world == 1 and a.scene == "car_pt" else None,
+        have_pmc = pmc is not None and world == 1 and all(k.get("pmc") for k in per_kernel)
+        pipeline = {"requested_bytes_per_step": pipeline_req / max(a.steps, 1), "requested_rate_gbs": pipeline_req / dt / 1e9}
+        if have_pmc:
+            insts = sum(k["pmc"]["valu_wave_instructions"] * k["launches"] for k in per_kernel)
+            for cat, sym in (("generate", "k_generate"), ("finish", "k_finish")):
+                if pmc_of(pmc, sym):
+                    insts += pmc_of(pmc, sym)["valu_wave_instructions"] * out["kernel_launches"].get(cat, 0)
+            hbm = sum(k["pmc"]["hbm_bytes"] * k["launches"] for k in per_kernel)
+            pipeline.update({
+                "source": PMC_SOURCE + "; multiplied by this run's launch counts and divided by this run's wall time",
+                "valu_issue": {"wave_instructions_per_step": insts / max(a.steps, 1), "achieved": insts / dt / 1e9,
+                               "peak": VALU_PEAK_PER_S / 1e9, "unit": "G wave64 vector instructions/s", "frac": insts / dt / VALU_PEAK_PER_S,
+                               "frac_at_measured_clock": insts / dt / (N_SIMD * sclk_hz / 4.0) if sclk_hz else None},
+                "hbm_traffic_rate_gbs": hbm / dt / 1e9, "hbm_frac": hbm / dt / 1e9 / HBM_PEAK_GBS})
+        roof = {"pipeline": pipeline,
                 "overlapped": {"streams": r_streams, "kernels": per_kernel,
-                               "requested_bytes_per_step": pipeline_req / max(a.steps, 1),
-                               "requested_rate_gbs": pipeline_req / dt / 1e9,
-                               # HBM-side bytes of the three kernels per second of the timed region (committed PMC
-                               # passes x launches), against the HBM peak: what the whole pipeline draws from memory
-                               "hbm_traffic_rate_gbs": (sum(k["traffic"] * k["launches"] for k in per_kernel) / dt / 1e9
-                                                        if all(k.get("traffic") for k in per_kernel) else None),
-                               "hbm_frac": (sum(k["traffic"] * k["launches"] for k in per_kernel) / dt / 1e9 / HBM_PEAK_GBS
-                                            if all(k.get("traffic") for k in per_kernel) else None),
-                               "note": "launch durations of the timed region: several streams share the GPU"}}
+                               "note": "launch durations of the timed region: several streams share the GPU, a launch's duration "
+                                       "includes the time it waits for the other streams' kernels"}}
         # one-stream repeat: each launch has the GPU to itself
         try:
             if a.no_exclusive or world > 1:
@@ -454,17 +569,13 @@ def main():
             # (in the timed region the streams' kernels share the CUs, and whose launches appear longest there
             # changes from run to run)
             dom = max(ex, key=lambda k: k["total_ms"])
-            roof.update({k: v for k, v in dom.items()})
+            roof.update(top_level(dom))
             roof["exclusive"] = {"streams": 1, "msamples_per_s": st1["samples"] / dt1 / 1e6, "kernels": ex,
                                  "requested_rate_gbs": sum(k["requested_bytes_per_launch"] * k["launches"] for k in ex) / dt1 / 1e9}
             roof["duration"] = "one-stream repeat after the timed region (a launch has the GPU to itself)"
-            if dom.get("pmc"):
-                roof["note"] = ("bytes against the roof of the memory level that serves them; what fills first in this kernel is "
-                                "vector-instruction issue (pmc.valu_issue_busy %.2f of the launch), and in the pipeline as a "
-                                "whole too (valu_issue)" % dom["pmc"]["valu_issue_busy"])
         except caster.CasterError as e:
             dom = max(per_kernel, key=lambda k: k["total_ms"])
-            roof.update({k: v for k, v in dom.items()})
+            roof.update(top_level(dom))
             roof["exclusive"] = {"error": str(e)}
             roof["duration"] = "timed region (launches of several streams overlap)"
         if counts is not None:
