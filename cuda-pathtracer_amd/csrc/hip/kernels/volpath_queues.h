@@ -40,220 +40,278 @@ __device__ inline V3 resolve_pending_vpt(const PathState& P, int slot, V3 Li, ui
   return Li + v3(P.beta_prev[slot]) * Ld;
 }
 
-__global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_vptq(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
+// What kind of event the queue entry `idx` will be, for grouping (a wrong answer costs divergence, never
+// correctness: the vertex below decides everything again for itself): a material type 0..5; kVptScatter, a
+// scattering event in the medium before the surface; kVptLight, the events that cost next to nothing (an emitter
+// seen by the camera or through a specular chain, an index-matched boundary crossed, a ray that left the scene
+// under an environment light); -1, nothing to do.  A ray that left the scene otherwise ends its path with no
+// vertex: what the path still owes from its previous vertex is added by k_finish.
+constexpr int kVptScatter = 6, kVptLight = 7, kVptLists = 8;
+__device__ inline int vptq_event_class(const DevScene& S, const PathState& P, const RayQueue& cur, uint32_t idx, bool env) {
+  const float4 h4 = cur.hit[idx];
+  const int prim = __float_as_int(h4.y);
+  if (prim < 0) return env && cur.d[idx].w >= 0.f ? kVptLight : -1;   // (tmax < 0: a slot outside the image)
+  const int slot = cur.slot[idx];
+  const uint32_t flags = __float_as_uint(P.li_flags[slot].w);
+  const int rmed = (int)((flags & kFMediumMask) >> kFMediumShift) - 1;
+  if (rmed != -1) {
+    // the free-flight distance Homogeneous::Sample is going to draw (medium.h:18-25)
+    uint32_t rng = __float_as_uint(P.beta_rng[slot].w);
+    MediumRec med;
+    load_medium(S, rmed, med);
+    int channel = fps::f2i_(rng_uniform(rng) * 3);
+    channel = channel == 3 ? 2 : channel;
+    const float sT = channel == 0 ? med.sigmaT.x : (channel == 1 ? med.sigmaT.y : med.sigmaT.z);
+    if (-fps::log_(1 - rng_uniform(rng)) / sT < h4.x) return kVptScatter;
+  }
+  const float4 ids = S.shade[(size_t)prim * kShadeF4 + 6];
+  const bool sees_emitters = (flags & kFBounceMask) == 0u || (flags & kFSpecular) != 0u;
+  if (__float_as_int(ids.x) == -1 || (sees_emitters && __float_as_int(ids.y) != -1)) return kVptLight;
+  const int t = __float_as_int(S.shade[(size_t)prim * kShadeF4 + 7].y);
+  return t >= 0 && t < kVptScatter ? t : kVptLight;
+}
+
+// One event of Volpath() (pathtracer.cu:1040-1223) at the queue entries `idx` of the lanes with `active` set.
+__device__ inline void vptq_events(const LaunchCtx& L, const RayQueue& cur, const StageArea& stage, StageCursor& sc, uint32_t idx,
+                                   bool active) {
   const DevScene& S = L.S;
   const PathState& P = L.P;
-  const uint32_t count = *cur.count;
-  const uint32_t sbase = blockIdx.x * stage.region_cap;
-  uint32_t n_next = 0, n_shadow = 0, n_probe = 0;
-  CASTER_FOR_ROUNDS_VPTQ(r, count) {
-    uint32_t idx = r * kWave + threadIdx.x;
-    bool want_next = false, want_shadow = false, want_probe = false;
-    int slot = 0;
-    V3 no = v3(0, 0, 0), nd = v3(0, 0, 1), so = no, sd = nd, po = no, pd = nd;
-    float stmax = 0.f;
-    if (idx < count) {
-      slot = cur.slot[idx];
-      float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
-      if (d4.w >= 0.f || __float_as_int(h4.y) >= 0) {
-        V3 ro = v3(o4), rd = v3(d4);
-        Hit h;
-        h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
-        float4 br = P.beta_rng[slot], lf = P.li_flags[slot];
-        V3 beta = v3(br), Li = v3(lf);
-        uint32_t rng = __float_as_uint(br.w), flags = __float_as_uint(lf.w);
-        int bounces = (int)(flags & kFBounceMask);
-        bool specular = (flags & kFSpecular) != 0;
-        int rmed = (int)((flags & kFMediumMask) >> kFMediumShift) - 1;
-        int crossings = (int)__float_as_uint(P.beta_prev[slot].w);
-        if (flags & kFPending) Li = resolve_pending_vpt(P, slot, Li, flags);
-        uint32_t pending = 0;
-        int nmed = rmed;
-        bool alive = true;
-        bool count_bounce = true;
-        if (h.prim < 0) {
-          if ((bounces == 0 || specular) && S.inf.valid) Li = Li + beta * inf_le(S.inf, rd);
-          alive = false;
-        } else {
-          Isect is;
-          load_isect(S, ro, rd, h, is);
-          V3 pos = is.pos, nor = is.n, dpdu = is.dpdu;
-          V2 uv = is.uv;
-          float rtmax = h.t;  // the reference's r.tmax after Intersect
-          float sampledDist = 0.f;
-          bool sampledMedium = false;
-          MediumRec med;
-          med.g = 0.f;
-          if (rmed != -1) {
-            // Homogeneous::Sample (medium.h:18-38)
-            load_medium(S, rmed, med);
-            int channel = fps::f2i_(rng_uniform(rng) * 3);
-            channel = channel == 3 ? 2 : channel;
-            float sT = channel == 0 ? med.sigmaT.x : (channel == 1 ? med.sigmaT.y : med.sigmaT.z);
-            float dist = -fps::log_(1 - rng_uniform(rng)) / sT;
-            dist = dist < rtmax ? dist : rtmax;
-            sampledMedium = dist < rtmax;
-            if (sampledMedium) sampledDist = dist;
-            V3 Tr = vexp(med.sigmaT * -dist);
-            V3 density = sampledMedium ? (med.sigmaT * Tr) : Tr;
-            float pdf = 0;
-            pdf += density.x; pdf += density.y; pdf += density.z;
-            pdf /= 3.f;
-            if (pdf == 0) pdf = 1;
-            beta = beta * (sampledMedium ? (Tr * med.sigmaS / pdf) : (Tr / pdf));
+  bool want_next = false, want_shadow = false, want_probe = false;
+  int slot = 0;
+  V3 no = v3(0, 0, 0), nd = v3(0, 0, 1), so = no, sd = nd, po = no, pd = nd;
+  float stmax = 0.f;
+  if (active) {
+    slot = cur.slot[idx];
+    float4 o4 = cur.o[idx], d4 = cur.d[idx], h4 = cur.hit[idx];
+    V3 ro = v3(o4), rd = v3(d4);
+    Hit h;
+    h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+    float4 br = P.beta_rng[slot], lf = P.li_flags[slot];
+    V3 beta = v3(br), Li = v3(lf);
+    uint32_t rng = __float_as_uint(br.w), flags = __float_as_uint(lf.w);
+    int bounces = (int)(flags & kFBounceMask);
+    bool specular = (flags & kFSpecular) != 0;
+    int rmed = (int)((flags & kFMediumMask) >> kFMediumShift) - 1;
+    if (flags & kFPending) Li = resolve_pending_vpt(P, slot, Li, flags);
+    uint32_t pending = 0;
+    int nmed = rmed;
+    bool alive = true;
+    bool count_bounce = true;
+    if (h.prim < 0) {
+      if ((bounces == 0 || specular) && S.inf.valid) Li = Li + beta * inf_le(S.inf, rd);
+      alive = false;
+    } else {
+      const float rtmax = h.t;  // the reference's r.tmax after Intersect
+      float sampledDist = 0.f;
+      bool sampledMedium = false;
+      MediumRec med;
+      med.g = 0.f; med.type = 0;
+      if (rmed != -1) {
+        load_medium(S, rmed, med);
+        medium_sample(S, rmed, med, ro, rd, rtmax, rng, beta, sampledDist, sampledMedium);   // (no density grid on this path)
+      }
+      if (is_black(beta)) {
+        alive = false;
+      } else if (sampledMedium) {
+        // a scattering event: light sample with the phase function as the BSDF, then a new direction
+        const V3 samplePos = ro + sampledDist * rd;
+        V3 radiance, ldir;
+        float ltmax, lightPdf, choicePdf;
+        sample_one_light(S, rng, samplePos, radiance, ldir, ltmax, lightPdf, choicePdf);
+        if (!is_black(radiance)) {
+          want_shadow = true;
+          so = samplePos; sd = ldir; stmax = ltmax;
+          P.pend_x[slot] = f4(beta, phase_eval(med, -rd, ldir));
+          P.pend_z[slot] = f4(radiance, lightPdf * choicePdf);
+          P.pend_w[slot] = f4(v3(1.f, 1.f, 1.f), (uint32_t)rmed);
+          pending = kFPending | kFPendingM;
+        }
+        const float ux = rng_uniform(rng);
+        const float uy = rng_uniform(rng);
+        no = samplePos; nd = phase_sample(med, ux, uy); nmed = rmed;
+        specular = false;
+      } else {
+      // (the intersection record is only built for the events that happen at the surface: in a dense medium most
+      // events are scattering events, which never look at it)
+      Isect is;
+      load_isect(S, ro, rd, h, is);
+      const V3 pos = is.pos, nor = is.n;
+      if ((bounces == 0 || specular) && is.light != -1) {
+        V3 tr = v3(1.f, 1.f, 1.f);
+        if (rmed != -1) tr = vexp(med.sigmaT * (-rtmax));
+        LightRec l;
+        load_light(S, is.light, l);
+        V3 le = dot(nor, -rd) > 0.f ? l.radiance : v3(0, 0, 0);
+        Li = Li + tr * beta * le;
+        alive = false;
+      } else if (is.mat == -1) {
+        // (the number of boundaries crossed so far rides in beta_prev.w, which only this event and a vertex
+        // that leaves a term pending touch)
+        const uint32_t crossings = __float_as_uint(P.beta_prev[slot].w) + 1u;
+        if (crossings > (uint32_t)kMaxCrossings) alive = false;
+        P.beta_prev[slot] = make_float4(0, 0, 0, __uint_as_float(crossings));
+        count_bounce = false;
+        nmed = dot(rd, is.n) > 0 ? is.med_out : is.med_in;
+        no = pos; nd = rd;
+      } else {
+        Mat m;
+        load_mat(S, is.mat, m);
+        const bool delta = is_delta(m.type);
+        // every random number of the vertex, in the reference's order: light choice and point (3), light
+        // probe (3), continuation (3) -- a specular surface draws the last three only
+        V3 radiance = v3(0, 0, 0), ldir = v3(0, 0, 1), us = v3(0, 0, 0), u;
+        float ltmax = 0.f, lightPdf = 1.f, choicePdf = 1.f;
+        if (!delta) {
+          sample_one_light(S, rng, pos, radiance, ldir, ltmax, lightPdf, choicePdf);
+          us.x = rng_uniform(rng); us.y = rng_uniform(rng); us.z = rng_uniform(rng);
+        }
+        u.x = rng_uniform(rng); u.y = rng_uniform(rng); u.z = rng_uniform(rng);
+        // the material is asked once: the light's direction, a direction for the light probe, the continuation
+        const bool lit = !is_black(radiance);
+        V3 lfr = v3(0, 0, 0), mo = v3(0, 0, 1), mfr = v3(0, 0, 0), wo2 = v3(0, 0, 1), fr2 = v3(0, 0, 0);
+        float lpdf = 0.f, mpdf = 0.f, pdf2 = 0.f;
+        with_lobe(S, m, Surface{-rd, nor, is.dpdu}, is.uv, [&](const auto& lobe) {
+          if (!lobe.kDelta) {
+            if (lit) lobe.eval(ldir, lfr, lpdf);
+            lobe.sample(us, true, mo, mfr, mpdf);
           }
-          if (is_black(beta)) {
-            alive = false;
-          } else if (sampledMedium) {
-            V3 samplePos = ro + sampledDist * rd;
-            V3 radiance, ldir;
-            float ltmax, lightPdf, choicePdf;
-            sample_one_light(S, rng, samplePos, radiance, ldir, ltmax, lightPdf, choicePdf);
-            // Medium::Phase / SamplePhase (medium.h:146-186)
-            float phase;
-            if (med.g == 0) phase = ONE_OVER_FOUR_PI;
-            else {
-              float costheta = dot(-rd, ldir);
-              float cubicTerm = (1.f + med.g * med.g - 2.f * med.g * costheta);
-              phase = ONE_OVER_FOUR_PI * (1.f - med.g * med.g) / sqrtf(cubicTerm * cubicTerm * cubicTerm);
-            }
-            if (!is_black(radiance)) {
-              want_shadow = true;
-              so = samplePos; sd = ldir; stmax = ltmax;
-              P.pend_x[slot] = f4(beta, phase);
-              P.pend_z[slot] = f4(radiance, lightPdf * choicePdf);
-              P.pend_w[slot] = f4(v3(1.f, 1.f, 1.f), (uint32_t)rmed);
-              pending = kFPending | kFPendingM;
-            }
-            float ux = rng_uniform(rng);
-            float uy = rng_uniform(rng);
-            V3 dir;
-            if (med.g == 0) {
-              float pdf;
-              dir = uniform_sphere(ux, uy, pdf);
-            } else {
-              float g = med.g, costheta;
-              if (fabsf(g) < 1e-3f) costheta = 1.f - 2.f * ux;
-              else {
-                float sqrtTerm = (1.f - g * g) / (1.f - g + 2.f * g * ux);
-                costheta = (1.f + g * g - sqrtTerm * sqrtTerm) / (2.f * g);
-              }
-              float sintheta = sqrtf(1.f - costheta * costheta);
-              float phi = TWOPI * uy;
-              float sinphi = fps::sin_(phi), cosphi = fps::cos_(phi);
-              dir = v3(sintheta * cosphi, sintheta * sinphi, costheta);
-            }
-            no = samplePos; nd = dir; nmed = rmed;
-            specular = false;
-          } else {
-            bool emitter = (bounces == 0 || specular) && is.light != -1;
-            if (emitter) {
-              V3 tr = v3(1.f, 1.f, 1.f);
-              if (rmed != -1) tr = vexp(med.sigmaT * (-rtmax));
-              LightRec l;
-              load_light(S, is.light, l);
-              V3 le = dot(nor, -rd) > 0.f ? l.radiance : v3(0, 0, 0);
-              Li = Li + tr * beta * le;
-              alive = false;
-            } else if (is.mat == -1) {
-              if (++crossings > kMaxCrossings) alive = false;
-              count_bounce = false;
-              nmed = dot(rd, is.n) > 0 ? is.med_out : is.med_in;
-              no = pos; nd = rd;
-            } else {
-              Mat m;
-              load_mat(S, is.mat, m);
-              resolve_texture(S, m, uv);
-              if (!is_delta(m.type)) {
-                V3 radiance, ldir;
-                float ltmax, lightPdf, choicePdf;
-                sample_one_light(S, rng, pos, radiance, ldir, ltmax, lightPdf, choicePdf);
-                float cosl = 0.f;
-                if (!is_black(radiance)) {
-                  V3 fr;
-                  float samplePdf;
-                  eval_bsdf(S, m, -rd, ldir, nor, uv, dpdu, fr, samplePdf);
-                  float weight = power_heuristic(lightPdf * choicePdf, samplePdf);
-                  want_shadow = true;
-                  so = pos; sd = ldir; stmax = ltmax;
-                  cosl = fabsf(dot(nor, ldir));
-                  P.pend_x[slot] = f4(fr, weight);
-                  P.pend_z[slot] = f4(radiance, lightPdf * choicePdf);
-                  P.pend_w[slot] = f4(v3(1.f, 1.f, 1.f), (uint32_t)rmed);
-                  pending |= kFPendingX;
-                }
-                V3 us;
-                us.x = rng_uniform(rng); us.y = rng_uniform(rng); us.z = rng_uniform(rng);
-                V3 mo, mfr;
-                float mpdf;
-                sample_bsdf(S, m, -rd, nor, uv, dpdu, us, mo, mfr, mpdf);
-                float absdot = 0.f;
-                if (!is_black(mfr) && mpdf != 0) {
-                  want_probe = true;
-                  po = pos; pd = mo;
-                  absdot = fabsf(dot(mo, nor));
-                  P.pend_y[slot] = f4(mfr, mpdf);
-                  pending |= kFPendingY;
-                }
-                // Li += beta * Ld: with neither part present that adds beta * 0, which only
-                // matters for a non-finite beta (the sample then turns NaN and is dropped)
-                bool finite_beta = fabsf(beta.x) < INFINITY && fabsf(beta.y) < INFINITY && fabsf(beta.z) < INFINITY;
-                if (pending || !finite_beta) {
-                  pending |= kFPending;
-                  P.pend_v[slot] = make_float4(absdot, cosl, __int_as_float(rmed), 0.f);
-                }
-              }
-              V3 u;
-              u.x = rng_uniform(rng); u.y = rng_uniform(rng); u.z = rng_uniform(rng);
-              V3 wo2, fr2;
-              float pdf2;
-              // the pending term keeps the throughput the vertex was reached with
-              V3 beta_here = beta;
-              sample_bsdf(S, m, -rd, nor, uv, dpdu, u, wo2, fr2, pdf2);
-              if (is_black(fr2)) {
-                alive = false;
-              } else {
-                beta = beta * (fr2 * fabsf(dot(nor, wo2)) / pdf2);
-                specular = is_delta(m.type);
-                int mm = dot(wo2, nor) > 0 ? is.med_out : is.med_in;
-                mm = dot(-rd, nor) * dot(wo2, nor) > 0 ? rmed : mm;
-                nmed = mm;
-                no = pos; nd = wo2;
-              }
-              if (pending & kFPending) {
-                P.beta_prev[slot] = f4(beta_here, (uint32_t)crossings);
-                pending |= 1u << 31;  // beta_prev written
-              }
+          lobe.sample(u, true, wo2, fr2, pdf2);
+        });
+        if (!delta) {
+          float cosl = 0.f, absdot = 0.f;
+          if (lit) {
+            const float weight = power_heuristic(lightPdf * choicePdf, lpdf);
+            want_shadow = true;
+            so = pos; sd = ldir; stmax = ltmax;
+            cosl = fabsf(dot(nor, ldir));
+            P.pend_x[slot] = f4(lfr, weight);
+            P.pend_z[slot] = f4(radiance, lightPdf * choicePdf);
+            P.pend_w[slot] = f4(v3(1.f, 1.f, 1.f), (uint32_t)rmed);
+            pending |= kFPendingX;
+          }
+          if (!is_black(mfr) && mpdf != 0) {
+            // The probe contributes when its closest hit is an emitter, or the environment when it leaves the
+            // scene: without an environment, a ray that misses the padded bounds of all emitters is not sent
+            // (its term counts as the zero it would have come to).
+            float tn;
+            const bool reach = S.inf.valid || (S.n_lights > 0 && box_test(v3(S.emit_lo), v3(S.emit_hi), slab_ray(pos, mo), INFINITY,
+                                                                         S.box_scale, tn));
+            if (reach) {
+              want_probe = true;
+              po = pos; pd = mo;
+              absdot = fabsf(dot(mo, nor));
+              P.pend_y[slot] = f4(mfr, mpdf);
+              pending |= kFPendingY;
             }
           }
-          if (alive && count_bounce) {
-            if (bounces > 3) {
-              float illumate = fps::clamp_(1.f - luminance(beta), 0.f, 1.f);
-              if (rng_uniform(rng) < illumate) alive = false;
-              else beta = beta / (1 - illumate);
-            }
-          }
-          if (count_bounce) {
-            if (bounces + 1 >= S.maxDepth) alive = false;
-            bounces += 1;
+          // Li += beta * Ld: with neither part present that adds beta * 0, which only
+          // matters for a non-finite beta (the sample then turns NaN and is dropped)
+          const bool finite_beta = fabsf(beta.x) < INFINITY && fabsf(beta.y) < INFINITY && fabsf(beta.z) < INFINITY;
+          if (pending || !finite_beta) {
+            pending |= kFPending;
+            P.pend_v[slot] = make_float4(absdot, cosl, __int_as_float(rmed), 0.f);
+            // the pending term keeps the throughput the vertex was reached with
+            P.beta_prev[slot] = f4(beta, __float_as_uint(P.beta_prev[slot].w));
           }
         }
-        want_next = alive;
-        if (!(pending & (1u << 31))) P.beta_prev[slot] = make_float4(0, 0, 0, __uint_as_float((uint32_t)crossings));
-        pending &= ~(1u << 31);
-        flags = (uint32_t)bounces | (specular ? kFSpecular : 0u) | ((uint32_t)(nmed + 1) << kFMediumShift) | pending;
-        P.beta_rng[slot] = f4(beta, rng);
-        P.li_flags[slot] = f4(Li, flags);
+        if (is_black(fr2)) {
+          alive = false;
+        } else {
+          beta = beta * (fr2 * fabsf(dot(nor, wo2)) / pdf2);
+          specular = delta;
+          int mm = dot(wo2, nor) > 0 ? is.med_out : is.med_in;
+          mm = dot(-rd, nor) * dot(wo2, nor) > 0 ? rmed : mm;
+          nmed = mm;
+          no = pos; nd = wo2;
+        }
+      }
+      }
+      if (alive && count_bounce && bounces > 3) {
+        float illumate = fps::clamp_(1.f - luminance(beta), 0.f, 1.f);
+        if (rng_uniform(rng) < illumate) alive = false;
+        else beta = beta / (1 - illumate);
+      }
+      if (count_bounce) {
+        if (bounces + 1 >= S.maxDepth) alive = false;
+        bounces += 1;
       }
     }
-    stage_push(stage.next, sbase, n_next, want_next, slot, no, -1, nd, INFINITY);
-    stage_push(stage.shadow, sbase, n_shadow, want_shadow, slot, so, -1, sd, stmax);
-    stage_push(stage.probe, sbase, n_probe, want_probe, slot, po, -1, pd, INFINITY);
+    want_next = alive;
+    flags = (uint32_t)bounces | (specular ? kFSpecular : 0u) | ((uint32_t)(nmed + 1) << kFMediumShift) | pending;
+    P.beta_rng[slot] = f4(beta, rng);
+    P.li_flags[slot] = f4(Li, flags);
   }
-  __syncthreads();
-  stage_flush(stage.next, sbase, n_next, out.next);
-  stage_flush(stage.shadow, sbase, n_shadow, out.shadow);
-  stage_flush(stage.probe, sbase, n_probe, out.probe);
+  stage_push(stage.next, sc.base, sc.n_next, want_next, slot, no, -1, nd, INFINITY);
+  stage_push(stage.shadow, sc.base, sc.n_shadow, want_shadow, slot, so, -1, sd, stmax);
+  stage_push(stage.probe, sc.base, sc.n_probe, want_probe, slot, po, -1, pd, INFINITY);
+}
+
+// The shade stage of the volumetric integrator on queues.  As the path tracer's (k_shade_pt): a wavefront sorts the
+// entries of a round into short lists in LDS by the kind of event they will be, and runs the event code for 64
+// entries of one kind at a time -- a scattering event in the medium, one material's vertex, or the cheap events --
+// so that the lanes of a group run the same code; rays that left the scene take no lane at all.
+// (Sorted by kind -- CASTER_VPTQ_SORT 1 -- the Cornell box in fog runs at 432 Msamples/s, with one list for whatever
+// needs an event at 500, against 448 for a lane per queue entry: the events of this integrator are cheap next to
+// the sixteen path-state records a vertex gathers by slot, and a group picked from a wider window of the queue
+// touches more lines of each; what pays is that the rays that left the scene take no lane.)
+#ifndef CASTER_VPTQ_SORT
+#define CASTER_VPTQ_SORT 0
+#endif
+__global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_vptq(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage) {
+  constexpr int kLists = CASTER_VPTQ_SORT ? kVptLists : 1;
+  __shared__ uint32_t s_list[kLists][kShadeListCap];
+  const DevScene& S = L.S;
+  const uint32_t count = *cur.count;
+  const uint32_t lane = threadIdx.x;
+  StageCursor sc{blockIdx.x * stage.region_cap, blockIdx.x * stage.region_cap, 0u, 0u, 0u};
+  uint32_t q_head = 0, q_len = 0;   // ring buffers: lane c keeps the start and the length of list c
+  const bool env = S.inf.valid != 0;
+  auto take_group = [&](int c, uint32_t n) {   // the first n (<= 64) entries of list c, one per lane
+    uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)q_head, c);
+    uint32_t my = s_list[c][(head + lane) & (kShadeListCap - 1)];
+    if ((int)lane == c) { q_head = (q_head + n) & (kShadeListCap - 1); q_len -= n; }
+    return my;
+  };
+  CASTER_FOR_ROUNDS_VPTQ(r, count) {
+    const uint32_t idx = r * kWave + lane;
+    int cls = -1;
+    if (idx < count) {
+      if (CASTER_VPTQ_SORT) cls = vptq_event_class(S, L.P, cur, idx, env);
+      else cls = __float_as_int(cur.hit[idx].y) >= 0 || (env && cur.d[idx].w >= 0.f) ? 0 : -1;
+    }
+    unsigned long long todo = lane_ballot(cls >= 0);
+    while (todo) {
+      int first = __builtin_ctzll(todo);
+      int c = __builtin_amdgcn_readlane(cls, first);
+      unsigned long long mine = lane_ballot(cls == c);
+      uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)q_head, c);
+      uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)q_len, c);
+      if (cls == c)
+        s_list[c][(head + len + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))) & (kShadeListCap - 1)] = idx;
+      if ((int)lane == c) q_len += (uint32_t)__popcll(mine);
+      todo &= ~mine;
+    }
+    __syncthreads();
+    unsigned long long full = lane_ballot(lane < (uint32_t)kLists && q_len >= (uint32_t)kWave);
+    while (full) {
+      int c = __builtin_ctzll(full);
+      uint32_t my = take_group(c, kWave);
+      vptq_events(L, cur, stage, sc, my, true);
+      full = lane_ballot(lane < (uint32_t)kLists && q_len >= (uint32_t)kWave);
+    }
+    __syncthreads();
+  }
+  // what is left in the lists
+  for (int c = 0; c < kLists; ++c) {
+    uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)q_len, c);
+    if (n == 0) continue;
+    uint32_t my = take_group(c, n);
+    vptq_events(L, cur, stage, sc, my, lane < n);
+  }
+  __syncthreads();  // the copies below read what other lanes of this wavefront staged
+  stage_flush(stage.next, sc.base, sc.n_next, out.next);
+  stage_flush(stage.shadow, sc.base, sc.n_shadow, out.shadow);
+  stage_flush(stage.probe, sc.base, sc.n_probe, out.probe);
 }
 
 // One segment of Tr() (pathtracer.cu:307-331) for every shadow ray whose closest
@@ -286,10 +344,13 @@ __global__ __launch_bounds__(kWave) void k_tr_step(LaunchCtx L, RayQueue cur, Ra
       V3 n = v3(0, 0, 0);
       bool opaque = false;
       if (found) {
-        Isect is;
-        load_isect(S, o, d, h, is);
-        med_in = is.med_in; med_out = is.med_out; n = is.n;
-        opaque = is.mat != -1;
+        // (an opaque hit ends the ray whatever its normal: the material index is looked at first)
+        opaque = __float_as_int(S.shade[(size_t)h.prim * kShadeF4 + 6].x) != -1;
+        if (!opaque) {
+          Isect is;
+          load_isect(S, o, d, h, is);
+          med_in = is.med_in; med_out = is.med_out; n = is.n;
+        }
       }
       if (opaque) {
         tr = v3(0, 0, 0);
