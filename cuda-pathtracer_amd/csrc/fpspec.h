@@ -52,10 +52,15 @@ CASTER_HD float clamp_(float v, float lo, float hi) { return fmin_(fmax_(v, lo),
 // becomes the multiplicand of the fma that adds the second; a difference of products keeps its
 // second product rounded).
 CASTER_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#ifdef CASTER_FPS_DIAG_UNFUSED_DOT   // diagnosis only: the products unfused
+CASTER_HD float dot3_(float ax, float ay, float az, float bx, float by, float bz) { return ax * bx + ay * by + az * bz; }
+CASTER_HD float diffprod_(float a, float b, float c, float d) { return a * b - c * d; }
+#else
 CASTER_HD float dot3_(float ax, float ay, float az, float bx, float by, float bz) {
   return fma_(az, bz, fma_(ax, bx, ay * by));
 }
 CASTER_HD float diffprod_(float a, float b, float c, float d) { return fma_(a, b, -(c * d)); }
+#endif
 
 // One plane of the slab test (bbox.h:76-84: (plane - origin) * (1 / direction)), for a ray that carries
 // noi = -(origin * inv) per axis.  FUSED: fma(plane, inv, noi) -- one rounding of (plane - origin) * inv
@@ -65,6 +70,9 @@ CASTER_HD float diffprod_(float a, float b, float c, float d) { return fma_(a, b
 // direction component of zero, a non-finite origin, or origin * inv overflowing) keeps the reference's form
 // for all its box tests: there inf - inf would make planes vanish from the test.
 CASTER_HD bool slab_fused_(float noix, float noiy, float noiz) {
+#ifdef CASTER_FPS_DIAG_UNFUSED_SLAB   // diagnosis only: every ray keeps the reference's form
+  return false;
+#endif
   return fabsf(noix) < INFINITY && fabsf(noiy) < INFINITY && fabsf(noiz) < INFINITY;
 }
 CASTER_HD float slab_plane_(float plane, float o, float inv, float noi, bool fused) {

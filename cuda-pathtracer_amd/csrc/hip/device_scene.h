@@ -69,6 +69,7 @@ struct DevScene {
   float epsilon;
   float g1, g2, g3;     // pbrt gamma(1..3), as the reference computes them
   float box_scale;      // 1 + 2*gamma(3)
+  float far_t;          // no hit is looked for farther along a ray than this (Scene::far_t)
   float emit_lo[3], emit_hi[3];  // box around all emissive triangles, padded far beyond rounding error
   int integrator, maxDepth;
   float maxDist;

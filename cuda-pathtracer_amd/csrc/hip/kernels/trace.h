@@ -122,6 +122,11 @@ __device__ unsigned long long g_walk_stats[2][16];
 #else
 #define CASTER_WS(i, v)
 #endif
+#ifdef CASTER_DEBUG_SLOW_RAYS
+// diagnosis builds only: rays that take more than CASTER_DEBUG_SLOW_RAYS steps are recorded here
+__device__ unsigned int g_slow_count;
+__device__ float g_slow[256][12];
+#endif
 // One ray of a lane.
 #ifndef CASTER_WALK_KEEP_NOI
 #define CASTER_WALK_KEEP_NOI 1   // 1: a ray keeps -(origin / direction) in registers; 0: three multiplies in every node step
@@ -138,6 +143,9 @@ struct WalkRay {
   int pend;  // a leaf waiting for its primitives to be tested (same encoding), kRefEmpty
   int sp;    // height of its stack
   int occluded;
+#ifdef CASTER_DEBUG_SLOW_RAYS
+  unsigned int steps = 0;
+#endif
   Octant oct;  // direction octant (node_step<.., OCT>); kOctPlain where origin / direction is not finite in
                // some component: the ray keeps to the plain slab test in the reference's form
 };
@@ -223,6 +231,17 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
   // Writes out ray `r` where it is finished.
   auto retire = [&](WalkRay& r) {
     if (r.idx >= 0 && r.cur == kRefEmpty && r.pend == kRefEmpty) {
+#ifdef CASTER_DEBUG_SLOW_RAYS
+      if (r.steps > (unsigned)CASTER_DEBUG_SLOW_RAYS) {
+        unsigned int k = atomicAdd(&g_slow_count, 1u);
+        if (k < 256u) {
+          float4 o4 = q.o[r.idx], d4 = q.d[r.idx];
+          float* g = g_slow[k];
+          g[0] = o4.x; g[1] = o4.y; g[2] = o4.z; g[3] = o4.w; g[4] = d4.x; g[5] = d4.y; g[6] = d4.z; g[7] = d4.w;
+          g[8] = (float)r.steps; g[9] = ANY ? 1.f : 0.f; g[10] = r.hit.t; g[11] = __int_as_float(r.hit.prim);
+        }
+      }
+#endif
       if (ANY) {
         if (r.occluded) {
           int slot = q.slot[r.idx];
@@ -292,14 +311,18 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
       r.oct = octant_of(r.inv, CASTER_OCTANT_GUARD && !fps::slab_fused_(noi.x, noi.y, noi.z));
       // every queued ray starts at the scene's epsilon; o.w carries a hit known
       // beforehand (a probe ray's nearest emitter, at distance tmax) or -1
-      r.hit.t = d4.w; r.hit.prim = __float_as_int(o4.w); r.hit.b1 = r.hit.b2 = 0.f;
+      // (no hit is looked for beyond the scene's far distance; a bound that is not a number gives way to it too)
+      r.hit.t = d4.w < S.far_t ? d4.w : S.far_t; r.hit.prim = __float_as_int(o4.w); r.hit.b1 = r.hit.b2 = 0.f;
       r.occluded = 0;
+#ifdef CASTER_DEBUG_SLOW_RAYS
+      r.steps = 0;
+#endif
       r.pend = kRefEmpty;
       r.sp = 0;
       // tmax < 0 marks a camera slot outside the image: nothing to trace.  (A tmax that is not
-      // a number -- a light sample at the vertex itself -- bounds nothing: every comparison with
-      // it fails, in the slab test and in the primitive tests, and the ray is traced unbounded,
-      // as the reference traces it.)
+      // a number -- a light sample at the vertex itself -- bounds nothing in the reference: every
+      // comparison with it fails, in the slab test and in the primitive tests; here such a ray is
+      // traced as far as the scene's far distance, like a ray without a bound.)
       r.cur = (!(d4.w < 0.f) && S.n_nodes) ? 0 : kRefEmpty;
     }
     chunk_next += give;
@@ -338,6 +361,9 @@ __global__ __launch_bounds__(kWave * kTraceBlockWaves, CASTER_TRACE_REG_WAVES) v
       if (n_busy == 0) break;
       if (more && kTraceRays * kWave - n_busy >= kRefill) break;
       CASTER_WS(4, n_busy);
+#ifdef CASTER_DEBUG_SLOW_RAYS
+      if (a.idx >= 0 && (a.cur != kRefEmpty || a.pend != kRefEmpty)) ++a.steps;
+#endif
       if (n_inner * CASTER_VOTE_NUM >= n_leaf * CASTER_VOTE_DEN) {
         CASTER_WS(0, 1);
         CASTER_WS(1, n_inner);

@@ -533,7 +533,7 @@ __device__ inline bool traverse(const DevScene& S, V3 o, V3 d, float tmin, float
   const SlabRay sr = slab_ray(o, d);
   float maxD = maxabs3(d);
   hit.prim = -1;
-  hit.t = tmax;
+  hit.t = tmax < S.far_t ? tmax : S.far_t;   // (no hit is looked for beyond the scene's far distance)
   hit.b1 = hit.b2 = 0.f;
   st.sp = 0;
   int cur = S.n_nodes ? 0 : kRefEmpty;

@@ -516,6 +516,7 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   S.epsilon = sc.epsilon;
   S.g1 = gamma_n(1); S.g2 = gamma_n(2); S.g3 = gamma_n(3);
   S.box_scale = 1 + 2 * S.g3;
+  S.far_t = sc.far_t;
   {
     // Bounds of the emitters, for rejecting BSDF-sampled probe rays that cannot reach one.  The
     // pad (1e-3 of the box's size and position) is some four orders of magnitude above the
@@ -1400,7 +1401,7 @@ int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, cons
   HIPCHECK(hipMemcpy(hit.data(), q.hit, n * sizeof(float4), hipMemcpyDeviceToHost));
   for (uint32_t i = 0; i < n; ++i) {
     memcpy(&prim[i], &hit[i].y, 4);
-    t[i] = hit[i].x;
+    t[i] = prim[i] < 0 ? tmax[i] : hit[i].x;   // (a ray that found nothing reports the bound it came with)
   }
   return CASTER_OK;
 }
@@ -1413,11 +1414,11 @@ __global__ void k_pack_rays(uint32_t n, const float* origins, const float* dirs,
     q.slot[i] = (int)i;
   }
 }
-__global__ void k_unpack_hits(uint32_t n, const float4* hit, int32_t* prim, float* t) {
+__global__ void k_unpack_hits(uint32_t n, const float4* hit, const float* tmax, int32_t* prim, float* t) {
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float4 h = hit[i];
     prim[i] = __float_as_int(h.y);
-    t[i] = h.x;
+    t[i] = __float_as_int(h.y) < 0 ? tmax[i] : h.x;   // (a ray that found nothing reports the bound it came with)
   }
 }
 
@@ -1455,7 +1456,7 @@ int caster_trace_rays_static(caster_renderer* r, uint32_t n, const float* origin
   hipLaunchKernelGGL(k_pack_rays, dim3(grid), dim3(256), 0, st, n, origins_dev, dirs_dev, tmax_dev, q);
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, q.count, n);
   hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, q, aux);
-  hipLaunchKernelGGL(k_unpack_hits, dim3(grid), dim3(256), 0, st, n, (const float4*)q.hit, prim_dev, t_dev);
+  hipLaunchKernelGGL(k_unpack_hits, dim3(grid), dim3(256), 0, st, n, (const float4*)q.hit, tmax_dev, prim_dev, t_dev);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipStreamSynchronize(st));
   return CASTER_OK;
@@ -1564,6 +1565,16 @@ int caster_reset_stats(caster_renderer* r) {
 
 uint32_t caster_iterations(const caster_renderer* r) { return r ? r->iterations : 0; }
 int caster_iters_in_flight(const caster_renderer* r) { return r ? r->iters_in_flight : 0; }
+
+#ifdef CASTER_DEBUG_SLOW_RAYS
+// diagnosis builds only: the rays k_trace recorded as slow (256 x 12 floats) and how many there were
+int caster_debug_slow_rays(float* out, unsigned int* count) {
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slow), sizeof(float) * 256 * 12));
+  HIPCHECK(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_slow_count), sizeof(unsigned int)));
+  return CASTER_OK;
+}
+#endif
 
 #ifdef CASTER_WALK_STATS
 // tuning builds only: copies and clears the k_trace step counters

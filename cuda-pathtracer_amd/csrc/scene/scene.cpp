@@ -499,6 +499,10 @@ bool load_impl(const char* filename, Scene& scene, std::string& err, BvhBuilder 
                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count(),
                       scene.nodes.size());
   scene.prims.swap(prims);
+  if (!scene.prims.empty()) {
+    f3 diag = scene.root_box.hi - scene.root_box.lo;
+    scene.far_t = kFarFactor * sqrtf(dot3(diag, diag));
+  }
   scene.lights.resize(light_radiance.size());
   for (size_t i = 0; i < scene.prims.size(); ++i) {
     int l = scene.prims[i].light;

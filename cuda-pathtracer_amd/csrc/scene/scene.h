@@ -123,6 +123,7 @@ struct Infinite {  // infinite.h:5-12
   f3 u{1, 0, 0}, v{0, 1, 0}, w_{0, 0, 1};
 };
 
+constexpr float kFarFactor = 16384.f;
 struct Scene {
   int width = 512, height = 512;
   float epsilon = 0.001f;
@@ -137,6 +138,13 @@ struct Scene {
   std::vector<Prim> prims;   // canonical (BVH leaf) order; hit ids index this
   std::vector<Node> nodes;
   BBox root_box;
+  // Hits farther along a ray than this are not looked for (kFarFactor times the diagonal of the scene's bounds; infinite
+  // for a scene without primitives).  The reference looks as far as +infinity (ray.h:12).  Real geometry lies within
+  // one diagonal of any point of the scene; what the triangle test reports at 10^8 diagonals is a rounding artefact
+  // of a ray all but parallel to a large triangle, and a path that goes on from there sends rays whose origin leaves
+  // single precision no room to tell one box of the tree from another: each such ray visits every node and every
+  // primitive (on any implementation, the reference's included) -- hundreds of milliseconds for one ray.
+  float far_t = INFINITY;
   std::vector<Light> lights;
   std::vector<float> light_cdf;  // lights.size()+1 (+1 with an environment light)
   Infinite infinite;

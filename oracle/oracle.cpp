@@ -39,6 +39,12 @@
 //     the light-sampling numbers and gets zero radiance;
 //   * at most kMaxCrossings index-matched boundary crossings per path and
 //     per transmittance ray;
+//   * no hit is looked for farther along a ray than 16384 diagonals of the scene's
+//     bounds (Scene::far_t; the reference looks to +infinity, ray.h:12): what the
+//     triangle test reports out there is a rounding artefact, and a path that
+//     went on from such a point would send rays that single precision cannot
+//     tell apart from one another at the scene, each of them visiting the whole
+//     tree;
 //   * the slab test drops a box entered beyond tmax * (1 + 2^-16), not beyond
 //     tmax itself (bbox.h:96): of two triangles sharing the edge a ray hits
 //     both are then always tested and the closest hit (smallest t, then
@@ -462,6 +468,8 @@ bool Intersect(const Ctx& cx, Ray& ray, Isect* isect, Counters& k, int kind) {
   const Ray ray0 = ray;
   k.c.rays[kind]++;
   if (cx.scene.nodes.empty()) return false;
+  // fixed convention (file header): no hit is looked for beyond the scene's far distance
+  ray.tmax = ray.tmax < cx.scene.far_t ? ray.tmax : cx.scene.far_t;
   std::vector<int>& stack = *([]() { static thread_local std::vector<int> s(256); return &s; })();
   int top = 0;
   bool ret = false;
@@ -483,6 +491,7 @@ bool Intersect(const Ctx& cx, Ray& ray, Isect* isect, Counters& k, int kind) {
     node_idx = stack[--top];
   }
   if (ret) k.c.hits[kind]++;
+  else ray.tmax = ray0.tmax;   // (a ray that found nothing keeps the bound it came with)
   if (g_debug_brute) DebugBrute(cx, ray0, false, ret, ret && isect ? isect->prim : -1, ray.tmax, kind);
   return ret;
 }
@@ -499,6 +508,8 @@ bool IntersectPrimitive(const Ctx& cx, Ray& ray, Counters& k, int kind) {
 static bool IntersectPrimitiveWalk(const Ctx& cx, Ray& ray, Counters& k, int kind) {
   k.c.rays[kind]++;
   if (cx.scene.nodes.empty()) return false;
+  const float tmax0 = ray.tmax;
+  ray.tmax = ray.tmax < cx.scene.far_t ? ray.tmax : cx.scene.far_t;   // fixed convention (file header)
   std::vector<int>& stack = *([]() { static thread_local std::vector<int> s(256); return &s; })();
   int top = 0;
   int node_idx = 0;
@@ -518,6 +529,7 @@ static bool IntersectPrimitiveWalk(const Ctx& cx, Ray& ray, Counters& k, int kin
     if (top == 0) break;
     node_idx = stack[--top];
   }
+  ray.tmax = tmax0;
   return false;
 }
 
