@@ -24,12 +24,17 @@ __device__ inline SlabRay slab_ray(V3 o, V3 d) {
 // rejected when behind the ray, empty, or beyond the current tmax; tmin is
 // not consulted.  Returns tNear through `tn`.
 __device__ inline bool box_test(V3 lo, V3 hi, const SlabRay& r, float tmax, float scale, float& tn) {
-  float txNear = fps::slab_plane_(lo.x, r.o.x, r.inv.x, r.noi.x, r.fused);
-  float txFar = fps::slab_plane_(hi.x, r.o.x, r.inv.x, r.noi.x, r.fused);
-  float tyNear = fps::slab_plane_(lo.y, r.o.y, r.inv.y, r.noi.y, r.fused);
-  float tyFar = fps::slab_plane_(hi.y, r.o.y, r.inv.y, r.noi.y, r.fused);
-  float tzNear = fps::slab_plane_(lo.z, r.o.z, r.inv.z, r.noi.z, r.fused);
-  float tzFar = fps::slab_plane_(hi.z, r.o.z, r.inv.z, r.noi.z, r.fused);
+  // Both forms of fps::slab_plane_ through one sequence, fma(plane - sub, inv, add): the fused form with sub = 0 and
+  // add = noi (plane - 0 is plane), the reference's form with sub = origin and add = 0 (a product plus zero is the
+  // rounded product, up to the sign of a zero, which no comparison below sees).  sub and add do not change along a
+  // walk, so a lane that walks the tree in a loop of its own sets them up once.
+  const V3 sub = r.fused ? v3(0.f, 0.f, 0.f) : r.o, add = r.fused ? r.noi : v3(0.f, 0.f, 0.f);
+  float txNear = fps::fma_(lo.x - sub.x, r.inv.x, add.x);
+  float txFar = fps::fma_(hi.x - sub.x, r.inv.x, add.x);
+  float tyNear = fps::fma_(lo.y - sub.y, r.inv.y, add.y);
+  float tyFar = fps::fma_(hi.y - sub.y, r.inv.y, add.y);
+  float tzNear = fps::fma_(lo.z - sub.z, r.inv.z, add.z);
+  float tzFar = fps::fma_(hi.z - sub.z, r.inv.z, add.z);
   // v_min_f32 / v_max_f32 drop a NaN operand exactly as fps::fmin_/fmax_ do;
   // they may differ in the sign of a zero result, which no comparison below sees.
   float tNear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(txNear, txFar), __builtin_fminf(tyNear, tyFar)),
