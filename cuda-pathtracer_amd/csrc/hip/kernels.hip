@@ -28,5 +28,6 @@
 #include "kernels/lighttrace.h"
 #include "kernels/bdpt.h"
 #include "kernels/volpath_queues.h"
+#include "kernels/volpath_hetero.h"
 #include "kernels/film.h"
 #include "kernels/hooks.h"

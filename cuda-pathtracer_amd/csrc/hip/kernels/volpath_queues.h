@@ -318,6 +318,10 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_shade_vptq(Launch
 // hit has just been found: an opaque hit ends the ray with zero transmittance,
 // otherwise the segment's medium attenuates it and, at an index-matched boundary,
 // the ray goes on from the hit in the medium on the other side.
+// HET: some medium of the scene is a density grid, whose transmittance (ratio tracking, medium.h:53-79) draws random
+// numbers: they come from the path's own generator, whose state waits in the path's state while the shadow ray is
+// under way (volpath_hetero.h), one segment after the other as Tr() walks them.
+template <bool HET>
 __global__ __launch_bounds__(kWave) void k_tr_step(LaunchCtx L, RayQueue cur, RayQueue next, StageArea stage) {
   const DevScene& S = L.S;
   const PathState& P = L.P;
@@ -357,9 +361,17 @@ __global__ __launch_bounds__(kWave) void k_tr_step(LaunchCtx L, RayQueue cur, Ra
       } else {
         float ray_tmax = found ? h.t : d4.w;
         if (medium != -1) {
-          MediumRec m;
-          load_medium(S, medium, m);
-          tr = tr * vexp(m.sigmaT * (-ray_tmax));
+          if (HET) {
+            float4 br = P.beta_rng[slot];
+            uint32_t rng = __float_as_uint(br.w);
+            tr = tr * medium_tr(S, medium, o, d, ray_tmax, rng);
+            br.w = __uint_as_float(rng);
+            P.beta_rng[slot] = br;
+          } else {
+            MediumRec m;
+            load_medium(S, medium, m);
+            tr = tr * vexp(m.sigmaT * (-ray_tmax));
+          }
         }
         if (found) {
           medium = dot(d, n) > 0 ? med_out : med_in;
@@ -380,6 +392,7 @@ __global__ __launch_bounds__(kWave) void k_tr_step(LaunchCtx L, RayQueue cur, Ra
 // than a few index-matched boundaries are rare) are walked to their end here,
 // lane by lane, so that a round of the integrator needs no queue length on the
 // host.
+template <bool HET>
 __global__ __launch_bounds__(kWave) void k_tr_finish(LaunchCtx L, RayQueue q, WalkAux aux) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
   Stack st{s_stack, aux.spill + (blockIdx.x * kWave + threadIdx.x), aux.spill_stride, 0};
@@ -395,6 +408,9 @@ __global__ __launch_bounds__(kWave) void k_tr_finish(LaunchCtx L, RayQueue q, Wa
     float4 w4 = P.pend_w[slot];
     V3 tr = v3(w4);
     int medium = __float_as_int(w4.w);
+    float4 br = make_float4(0, 0, 0, 0);
+    uint32_t rng = 1u;
+    if (HET) { br = P.beta_rng[slot]; rng = __float_as_uint(br.w); }
     for (int guard = 0; guard < kMaxCrossings; ++guard) {
       Hit h;
       ++segs;
@@ -409,15 +425,20 @@ __global__ __launch_bounds__(kWave) void k_tr_finish(LaunchCtx L, RayQueue q, Wa
       }
       float ray_tmax = found ? h.t : seg_tmax;
       if (medium != -1) {
-        MediumRec m;
-        load_medium(S, medium, m);
-        tr = tr * vexp(m.sigmaT * (-ray_tmax));
+        if (HET) {
+          tr = tr * medium_tr(S, medium, o, d, ray_tmax, rng);
+        } else {
+          MediumRec m;
+          load_medium(S, medium, m);
+          tr = tr * vexp(m.sigmaT * (-ray_tmax));
+        }
       }
       if (!found) break;
       medium = dot(d, n) > 0 ? med_out : med_in;
       seg_tmax = seg_tmax - ray_tmax;
       o = o + ray_tmax * d;
     }
+    if (HET) { br.w = __uint_as_float(rng); P.beta_rng[slot] = br; }
     P.pend_w[slot] = f4(tr, (uint32_t)medium);
   }
   for (int off = 32; off > 0; off >>= 1) segs += (uint32_t)__shfl_down((int)segs, off, 64);

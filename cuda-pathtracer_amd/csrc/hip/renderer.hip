@@ -348,7 +348,8 @@ struct caster_renderer {
   int bdpt_grid = 0;  // workgroups of k_bdpt (one sample per lane at a time)
   bool lt_queues = false;   // light tracing with its connection rays on queues (no density grid in the scene)
   bool probe_any = false;   // path tracer: probe rays ride the shadow queue as occlusion rays (few emitters, no environment)
-  bool vpt_queues = false;  // volumetric integrator with its shadow and probe rays on queues (no density grid in the scene)
+  bool vpt_queues = false;  // volumetric integrator with its shadow and probe rays on queues
+  bool vpt_hetero = false;  // ... in a scene with a density grid: the vertex in three phases (volpath_hetero.h)
   float* acc = nullptr;
   float* film_tmp = nullptr;
   int32_t* ids = nullptr;
@@ -572,7 +573,11 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
   // shade grid: one wavefront per block, as many as are resident at once
   {
     int per_cu = 8;
-    r->vpt_queues = sc.integrator == IT_VPT && !sc.has_heterogeneous;
+    // (CASTER_VPT_INKERNEL=1 in the environment keeps the one-kernel vertex for scenes with a density grid: a knob
+    // for tests and measurements)
+    const char* in_kernel = getenv("CASTER_VPT_INKERNEL");
+    r->vpt_queues = sc.integrator == IT_VPT && !(sc.has_heterogeneous && in_kernel && in_kernel[0] == '1');
+    r->vpt_hetero = r->vpt_queues && sc.has_heterogeneous;
     // Every probe ray of the path tracer then starts out with the nearest emitter on its line, and can be
     // settled in k_shade_pt<true> but for its visibility (see there): two launches less per bounce, for a
     // heavier shade kernel.  Against a closest-hit probe queue with a resolve kernel of its own, 1080p on
@@ -589,7 +594,7 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     // launches per round (Cornell box: 513 against 443 Msamples/s; 1.37 M triangles: 420 against 775)
     r->lt_queues = sc.integrator == IT_LT && !sc.has_heterogeneous && (sc.nodes.size() > 128 || !sc.media.empty());
     const void* fn = sc.integrator == IT_AO ? (const void*)k_shade_ao
-                     : sc.integrator == IT_VPT ? (r->vpt_queues ? (const void*)k_shade_vptq : (const void*)k_shade_vpt)
+                     : sc.integrator == IT_VPT ? (r->vpt_hetero ? (const void*)k_vpth<0> : r->vpt_queues ? (const void*)k_shade_vptq : (const void*)k_shade_vpt)
                      : sc.integrator == IT_LT ? (r->lt_queues ? (const void*)k_shade_lt<true> : (const void*)k_shade_lt<false>)
                                               : (const void*)k_shade_pt<false>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 8;
@@ -725,9 +730,11 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
       ScopedTimer t(r, st, CASTER_K_EXTEND);
       hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, q, aux_for(0));
     }
+    const bool het = r->vpt_hetero;
     {
       ScopedTimer t(r, st, CASTER_K_SHADE);
-      hipLaunchKernelGGL(k_shade_vptq, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
+      if (het) hipLaunchKernelGGL(k_vpth<0>, dim3(shade_grid), dim3(kWave), 0, st, L, q, ln.probe, out, ln.stage);
+      else hipLaunchKernelGGL(k_shade_vptq, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
     }
     RayQueue* tq[2] = {&ln.shadow, &ln.tr1};
     int tcur = 0;
@@ -740,17 +747,29 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
         ScopedTimer t(r, st, CASTER_K_SHADOW);
         hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, *tq[tcur], aux_for(1));
       }
-      hipLaunchKernelGGL(k_tr_step, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
+      if (het) hipLaunchKernelGGL(k_tr_step<true>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
+      else hipLaunchKernelGGL(k_tr_step<false>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
       hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, tq[tcur]->count, 0u);
       tcur ^= 1;
     }
     // whatever is still under way is walked to its end lane by lane
-    hipLaunchKernelGGL(k_tr_finish, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], ln.aux);
+    if (het) hipLaunchKernelGGL(k_tr_finish<true>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], ln.aux);
+    else hipLaunchKernelGGL(k_tr_finish<false>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], ln.aux);
+    if (het) {
+      // the paths that waited for their Tr(): a scattering event's new direction, a surface vertex's probe
+      ScopedTimer t(r, st, CASTER_K_SHADE);
+      hipLaunchKernelGGL(k_vpth<1>, dim3(shade_grid), dim3(kWave), 0, st, L, q, ln.probe, out, ln.stage);
+    }
     {
       ScopedTimer t(r, st, CASTER_K_PROBE);
       hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, ln.probe, aux_for(2));
     }
-    hipLaunchKernelGGL(k_probe_resolve_vpt, dim3(shade_grid), dim3(kWave), 0, st, L, ln.probe);
+    if (het) {
+      ScopedTimer t(r, st, CASTER_K_SHADE);
+      hipLaunchKernelGGL(k_vpth<2>, dim3(shade_grid), dim3(kWave), 0, st, L, q, ln.probe, out, ln.stage);
+    } else {
+      hipLaunchKernelGGL(k_probe_resolve_vpt, dim3(shade_grid), dim3(kWave), 0, st, L, ln.probe);
+    }
     hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)q.count, (const uint32_t*)nullptr,
                        (const uint32_t*)ln.probe.count, q.count, tq[tcur]->count, ln.probe.count, b == 0 ? live_rays : 0u,
                        ln.counters + 64, 3u * kWorkShards, r->work_init, 0u);
@@ -770,11 +789,11 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
         ScopedTimer t(r, st, CASTER_K_SHADOW);
         hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, *tq[tcur], aux_for(1));
       }
-      hipLaunchKernelGGL(k_tr_step, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
+      hipLaunchKernelGGL(k_tr_step<false>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
       hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, tq[tcur]->count, 0u);
       tcur ^= 1;
     }
-    hipLaunchKernelGGL(k_tr_finish, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], ln.aux);
+    hipLaunchKernelGGL(k_tr_finish<false>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], ln.aux);
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, tq[tcur]->count, 0u);
     {
       ScopedTimer t(r, st, CASTER_K_PROBE);

@@ -24,6 +24,7 @@ FRAMES = {
     "C3_stairs_1080p": ("stairs_pt", 1.0, 1920, 1080, 8, 16),     # 3.3e7 samples; lines and spheres on the railing
     "C4_cornell_fog_1024": ("cornell_vpt", 1.0, 1024, 1024, 16, 8),  # 8.4e6 samples; spheres inside the medium
     "C5_car_1080p": ("car_pt", 1.0, 1920, 1080, 8, 4),             # 8.3e6 samples; 1.37 M primitives
+    "X_cornell_smoke_512": ("cornell_smoke", 1.0, 512, 512, 16, 8),  # 2.1e6 samples; a density grid: the vertex in three phases
 }
 
 
@@ -56,3 +57,24 @@ def test_whole_frame_equals_oracle(caster, tmp_path, key):
         # one extension ray per path vertex on both sides (the GPU sends fewer shadow and probe rays:
         # it skips those whose term is zero whatever they hit)
         assert st["rays"][0] == c["rays"][0]
+
+
+def test_density_grid_vertex_in_phases_equals_the_vertex_in_one_kernel(caster, tmp_path, monkeypatch):
+    """A scene with a density grid is rendered with the volumetric vertex cut into three phases around its two
+    traced rays (the default), and -- CASTER_VPT_INKERNEL=1, a knob -- with the whole vertex and its walks in one
+    kernel: the same film bit for bit, the same extension rays and transmittance segments; the phased vertex sends
+    fewer probe rays (those that cannot reach an emitter)."""
+    path = gen_scenes.generate(str(tmp_path / "smoke"), "cornell_smoke", 1.0, 256, 256, 16)
+    sc = caster.Scene(path)
+    out = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("CASTER_VPT_INKERNEL", knob)
+        r = caster.Renderer(sc, 0, 4, 2)
+        r.render(1, 12, True)
+        out[knob] = (r.read_film(2), r.stats())
+        r.close()
+    monkeypatch.delenv("CASTER_VPT_INKERNEL")
+    np.testing.assert_array_equal(out["0"][0], out["1"][0])
+    a, b = out["0"][1], out["1"][1]
+    assert a["rays"][0] == b["rays"][0] and a["rays"][3] == b["rays"][3] and a["invalid"] == b["invalid"]
+    assert 0 < a["rays"][2] < b["rays"][2]
