@@ -311,7 +311,7 @@ inline bool TriIntersect(const Ctx& cx, const Prim& p, int id, Ray& ray, Isect* 
 }
 
 // sphere.h:24-91
-inline bool SphereIntersect(const Prim& p, int id, Ray& ray, Isect* isect) {
+inline bool SphereIntersect(const Prim& p, int id, Ray& ray, Isect* isect, uint64_t* box_rejects = nullptr) {
   V3 origin = v3(p.p0);
   float radius = p.w0;
   V3 op = ray.origin - origin;
@@ -343,7 +343,10 @@ inline bool SphereIntersect(const Prim& p, int id, Ray& ray, Isect* isect) {
     V3 rr = v3(radius, radius, radius);
     float tNear, tFar;
     SlabDistances(origin - rr, origin + rr, ray, tNear, tFar);
-    if (tNear > th * fps::kNearCullSlack) return false;
+    if (tNear > th * fps::kNearCullSlack) {
+      if (box_rejects) ++*box_rejects;
+      return false;
+    }
   }
   ray.tmax = th;
   if (isect) {
@@ -408,7 +411,7 @@ inline bool PrimIntersect(const Ctx& cx, int i, Ray& ray, Isect* isect, Counters
   if (p.type == caster::GT_TRIANGLE) { k.c.tris[kind]++; return TriIntersect(cx, p, i, ray, isect); }
   if (p.type == caster::GT_LINES) { k.c.lines[kind]++; return LineIntersect(p, i, ray, isect); }
   k.c.spheres[kind]++;
-  return SphereIntersect(p, i, ray, isect);
+  return SphereIntersect(p, i, ray, isect, &k.c.sphere_box_rejects);
 }
 
 // Test aid (oracle_debug_bruteforce): every ray is also tested against all primitives, and a walk
@@ -2035,6 +2038,7 @@ void add_counts(oracle_counts* dst, const oracle_counts& s) {
     dst->spheres[i] += s.spheres[i]; dst->lines[i] += s.lines[i]; dst->hits[i] += s.hits[i];
   }
   dst->samples += s.samples; dst->invalid += s.invalid; dst->bounces += s.bounces;
+  dst->sphere_box_rejects += s.sphere_box_rejects;
 }
 
 }  // namespace

@@ -13,11 +13,11 @@ LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 
 class Counts(C.Structure):
     _fields_ = [(n, C.c_uint64 * 4) for n in ("rays", "nodes", "tris", "spheres", "lines", "hits")] + [
-        ("samples", C.c_uint64), ("invalid", C.c_uint64), ("bounces", C.c_uint64)]
+        ("samples", C.c_uint64), ("invalid", C.c_uint64), ("bounces", C.c_uint64), ("sphere_box_rejects", C.c_uint64)]
 
     def as_dict(self):
         d = {n: list(getattr(self, n)) for n in ("rays", "nodes", "tris", "spheres", "lines", "hits")}
-        d.update(samples=self.samples, invalid=self.invalid, bounces=self.bounces)
+        d.update(samples=self.samples, invalid=self.invalid, bounces=self.bounces, sphere_box_rejects=self.sphere_box_rejects)
         return d
 
 

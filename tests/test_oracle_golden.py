@@ -194,3 +194,23 @@ def test_bidirectional_and_unidirectional_estimators_agree(tmp_path):
     assert 0.97 < ratio < 1.08, ratio
     rel = np.abs(bd - pt).sum(axis=2) / (pt.sum(axis=2) + 1e-3)
     assert np.median(rel) < 0.1, rel
+
+
+# Size of a declared deviation.  The reference's sphere test (sphere.h:24-66) assumes a unit direction; for the rays of
+# other lengths that leave a line or a sphere its roots are no distances, and a candidate in front of the point where
+# the ray enters the sphere's own bounding box is rejected here (oracle and renderer alike: the closest hit must not
+# depend on the order the tree is walked in).  The oracle counts the candidates the reference would have accepted and
+# this rule drops: a few in 10^4 samples where spheres are seen through other spheres or through a medium, none where
+# every ray has unit length.
+SPHERE_BOX_REJECTS = {"cornell_ao": 6, "cornell_pt": 0, "cornell_vpt": 57, "stairs_pt": 4, "car_env": 0}
+
+
+@pytest.mark.parametrize("key", sorted(SPHERE_BOX_REJECTS))
+def test_size_of_the_sphere_deviation(key):
+    o = ol.Oracle(os.path.join(GOLD, "scenes", key, "scene.json"))
+    c = ol.Counts()
+    o.render(1, 8, 4, counts=c)
+    d = c.as_dict()
+    print(key, "samples", d["samples"], "sphere tests", sum(d["spheres"]), "dropped by the rule", d["sphere_box_rejects"])
+    assert d["sphere_box_rejects"] == SPHERE_BOX_REJECTS[key]
+    assert d["sphere_box_rejects"] <= 2e-3 * d["samples"]
