@@ -26,14 +26,41 @@ __device__ inline float het_cell(const DevScene& S, const GridRec& g, V3 p) {  /
   return S.density[(size_t)g.off + (size_t)z * g.ny * g.nx + (size_t)y * g.nx + x];
 }
 __device__ inline float lerp_(float a, float b, float t) { return a + t * (b - a); }
+// Two cells next to each other in x: GetDensity (medium.h:124-129) of (x0, y, z) and (x1, y, z).  The eight lookups
+// of a trilinear sample are four such pairs, and the two cells of a pair are neighbours in memory: where both lie
+// inside the grid they come with one 8-byte load (the vector cache's rate of lane addresses is what a tracking loop
+// waits for, so four addresses per sample instead of eight).
+__device__ inline void het_cell_pair(const DevScene& S, const GridRec& g, int x0, int x1, int y, int z, float& a, float& b) {
+  a = 0.f; b = 0.f;
+  if (y < 0 || y > g.ny - 1 || z < 0 || z > g.nz - 1) return;
+  const bool in0 = x0 >= 0 && x0 <= g.nx - 1, in1 = x1 >= 0 && x1 <= g.nx - 1;
+  const float* row = S.density + ((size_t)g.off + (size_t)z * g.ny * g.nx + (size_t)y * g.nx);
+  if (in0 && in1 && x1 == x0 + 1) {
+    float2 v;
+    __builtin_memcpy(&v, row + x0, sizeof(v));   // (4-byte aligned)
+    a = v.x; b = v.y;
+  } else {
+    if (in0) a = row[x0];
+    if (in1) b = row[x1];
+  }
+}
 __device__ inline float het_density(const DevScene& S, const GridRec& g, V3 p) {  // medium.h:111-122
   V3 ps = v3(p.x * g.nx - .5f, p.y * g.ny - .5f, p.z * g.nz - .5f);
   V3 psi = v3(floorf(ps.x), floorf(ps.y), floorf(ps.z));
   V3 delta = ps - psi;
-  float d00 = lerp_(het_cell(S, g, psi), het_cell(S, g, psi + v3(1, 0, 0)), delta.x);
-  float d10 = lerp_(het_cell(S, g, psi + v3(0, 1, 0)), het_cell(S, g, psi + v3(1, 1, 0)), delta.x);
-  float d01 = lerp_(het_cell(S, g, psi + v3(0, 0, 1)), het_cell(S, g, psi + v3(1, 0, 1)), delta.x);
-  float d11 = lerp_(het_cell(S, g, psi + v3(0, 1, 1)), het_cell(S, g, psi + v3(1, 1, 1)), delta.x);
+  // (the reference adds 1 to the floored coordinate as a float and converts each corner by itself: so here)
+  const int x0 = fps::f2i_(psi.x), x1 = fps::f2i_(psi.x + 1.f);
+  const int y0 = fps::f2i_(psi.y), y1 = fps::f2i_(psi.y + 1.f);
+  const int z0 = fps::f2i_(psi.z), z1 = fps::f2i_(psi.z + 1.f);
+  float c000, c100, c010, c110, c001, c101, c011, c111;
+  het_cell_pair(S, g, x0, x1, y0, z0, c000, c100);
+  het_cell_pair(S, g, x0, x1, y1, z0, c010, c110);
+  het_cell_pair(S, g, x0, x1, y0, z1, c001, c101);
+  het_cell_pair(S, g, x0, x1, y1, z1, c011, c111);
+  float d00 = lerp_(c000, c100, delta.x);
+  float d10 = lerp_(c010, c110, delta.x);
+  float d01 = lerp_(c001, c101, delta.x);
+  float d11 = lerp_(c011, c111, delta.x);
   float d0 = lerp_(d00, d10, delta.y);
   float d1 = lerp_(d01, d11, delta.y);
   return lerp_(d0, d1, delta.z);

@@ -28,6 +28,243 @@ constexpr uint32_t kFStageShift = 29;               // li_flags bits 29..30: wha
 constexpr uint32_t kFStageMask = 3u << kFStageShift;
 enum : uint32_t { kStageNone = 0u, kStageTrScatter = 1u, kStageTrSurface = 2u, kStageProbe = 3u };
 
+// ---- tracking loops with lanes that refill ---------------------------------------------------------------------------
+// Delta tracking (the free flight through a density grid, medium.h:81-109) and ratio tracking (its transmittance,
+// medium.h:53-79) are loops whose trip count differs from ray to ray like a geometric distribution: with one queue
+// entry per lane and round, a wavefront runs as long as its longest loop and a quarter to a third of its lanes work.
+// The two kernels below give a lane its next queue entry as soon as it has finished one (as the traversal kernel
+// refills its lanes): every iteration of the wavefront's loop is one tracking step for all lanes that are in a loop,
+// then the lanes whose loop has ended write their result, and once enough lanes are free they take the next entries of
+// the wavefront's part of the queue.  Each entry still runs the reference's sequence of operations and draws.
+struct LaneFeed {
+  uint32_t next, end;   // the wavefront's part of the queue, the same in every lane
+};
+#ifndef CASTER_FEED_IDLE
+#define CASTER_FEED_IDLE 32
+#endif
+// The tracking kernels are slim (64-73 registers) and wait for memory most of the time: they are launched with this
+// multiple of the shade grid (which is sized for the vertex kernels' register count), up to 8 wavefronts per SIMD.
+#ifndef CASTER_TRACK_GRID_MUL
+#define CASTER_TRACK_GRID_MUL 2
+#endif
+constexpr uint32_t kTrackGridMul = CASTER_TRACK_GRID_MUL;   // (at most 8: a region holds 8 rounds more than an even share)
+constexpr int kFeedIdle = CASTER_FEED_IDLE;   // lanes free before the next entries are taken
+// Gives the free lanes the next entries: this lane's entry, or ~0u.
+__device__ inline uint32_t feed_take(LaneFeed& f, bool idle) {
+  const unsigned long long m = lane_ballot(idle);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t n_idle = (uint32_t)__popcll(m), avail = f.end - f.next, give = avail < n_idle ? avail : n_idle;
+  const uint32_t prefix = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  const uint32_t mine = (idle && prefix < give) ? f.next + prefix : ~0u;
+  f.next += give;
+  return mine;
+}
+__device__ inline LaneFeed feed_of(uint32_t count) {   // a contiguous part per wavefront, in whole rounds of 64
+  const uint32_t all = (count + kWave - 1) / kWave, per = (all + gridDim.x - 1) / gridDim.x;
+  const uint32_t r0 = blockIdx.x * per, r1 = r0 + per < all ? r0 + per : all;
+  LaneFeed f;
+  f.next = r0 < all ? r0 * kWave : count;
+  f.end = r1 * kWave < count ? r1 * kWave : count;
+  if (f.next > f.end) f.next = f.end;
+  return f;
+}
+// What a tracking loop keeps of its medium.
+struct TrackMedium {
+  GridRec g;
+  V3 ext;
+  float sigma, invMax;
+};
+__device__ inline void track_medium(const DevScene& S, int medium, const MediumRec& m, TrackMedium& t) {
+  load_grid(S, medium, t.g);
+  t.sigma = dot(m.sigmaT, v3(0.212671f, 0.715160f, 0.072169f));
+  t.ext = t.g.p1 - t.g.p0;
+  t.invMax = m.invMax;
+}
+
+// Medium::Sample (medium.h:18-38, :81-109) for every entry of the traced extension queue whose ray runs through a
+// medium and hit something: scales the path's beta, advances its generator, and leaves the distance of a scattering
+// event before the surface in the entry's o.w (which holds -1, "no hit known beforehand", otherwise).
+__global__ __launch_bounds__(kWave) void k_vpth_flight(LaunchCtx L, RayQueue cur) {
+  const DevScene& S = L.S;
+  const PathState& P = L.P;
+  LaneFeed feed = feed_of(*cur.count);
+  bool busy = false, looping = false;
+  uint32_t idx = 0, rng = 1u;
+  int slot = 0, iter = 0;
+  V3 ro = v3(0, 0, 0), rd = v3(0, 0, 1), beta = v3(0, 0, 0), scatter_scale = v3(0, 0, 0);
+  float rtmax = 0.f, dist = 0.f, sampledDist = 0.f;
+  bool sampledMedium = false;
+  TrackMedium tm;
+  tm.sigma = 1.f; tm.invMax = 1.f; tm.ext = v3(1, 1, 1);
+  tm.g.nx = tm.g.ny = tm.g.nz = 1; tm.g.off = 0; tm.g.iterMax = 1; tm.g.p0 = tm.g.p1 = v3(0, 0, 0);
+  for (;;) {
+    const int n_busy = __popcll(lane_ballot(busy));
+    if (feed.next < feed.end && kWave - n_busy >= kFeedIdle) {
+      const uint32_t mine = feed_take(feed, !busy);
+      if (mine != ~0u) {
+        // (the loads are written out level by level, so that a refill waits for three round trips to memory, not six)
+        const float4 h4 = cur.hit[mine], o4 = cur.o[mine], d4 = cur.d[mine];
+        const int s = cur.slot[mine];
+        const uint32_t flags = __float_as_uint(P.li_flags[s].w);
+        const float4 br = P.beta_rng[s];
+        const int rmed = (int)((flags & kFMediumMask) >> kFMediumShift) - 1;
+        if (__float_as_int(h4.y) >= 0 && rmed != -1) {
+          idx = mine; slot = s;
+          ro = v3(o4); rd = v3(d4); rtmax = h4.x;
+          beta = v3(br); rng = __float_as_uint(br.w);
+          MediumRec med;
+          load_medium(S, rmed, med);
+          track_medium(S, rmed, med, tm);   // (the record of a homogeneous medium has these fields too, unused)
+          busy = true;
+          sampledMedium = false; sampledDist = 0.f;
+          if (med.type == 0) {
+            medium_sample(S, rmed, med, ro, rd, rtmax, rng, beta, sampledDist, sampledMedium);   // (no loop in there)
+            looping = false;
+          } else {
+            scatter_scale = med.sigmaS / med.sigmaT;
+            dist = 0.f; iter = tm.g.iterMax;
+            looping = true;
+          }
+        }
+      }
+    } else if (n_busy == 0) {
+      break;   // (nothing under way and nothing left to take)
+    }
+    if (busy && looping) {   // one step of delta tracking (medium.h:88-104)
+      dist += -fps::log_(rng_uniform(rng)) * tm.invMax / tm.sigma;
+      if (dist >= rtmax) {
+        beta = beta * v3(1.f, 1.f, 1.f);
+        looping = false;
+      } else {
+        V3 p = ro + rd * dist;
+        p = (p - tm.g.p0) / tm.ext;
+        if (het_density(S, tm.g, p) * tm.invMax > rng_uniform(rng)) {
+          sampledDist = dist;
+          sampledMedium = true;
+          beta = beta * scatter_scale;
+          looping = false;
+        } else if (--iter == 0) {
+          beta = beta * v3(1.f, 1.f, 1.f);
+          looping = false;
+        }
+      }
+    }
+    if (busy && !looping) {
+      P.beta_rng[slot] = f4(beta, rng);
+      if (sampledMedium) cur.o[idx].w = sampledDist;
+      busy = false;
+    }
+  }
+}
+
+// One segment of Tr() for every shadow ray whose closest hit has just been found, where a medium may be a density
+// grid: k_tr_step<true> with lanes that refill.
+__global__ __launch_bounds__(kWave) void k_tr_step_grid(LaunchCtx L, RayQueue cur, RayQueue next, StageArea stage) {
+  const DevScene& S = L.S;
+  const PathState& P = L.P;
+  LaneFeed feed = feed_of(*cur.count);
+  // (launched with kTrackGridMul times the shade grid the staging regions are sized for: each wavefront's share of the
+  // queue, and with it the part of a region it can fill, is that much smaller)
+  const uint32_t sbase = blockIdx.x * (stage.region_cap / kTrackGridMul);
+  uint32_t n_next = 0;
+  bool busy = false, looping = false, found = false;
+  uint32_t rng = 1u;
+  int slot = 0, iter = 0, medium = -1, med_in = -1, med_out = -1;
+  V3 o = v3(0, 0, 0), d = v3(0, 0, 1), n = v3(0, 0, 0), tr = v3(0, 0, 0);
+  float seg_tmax = 0.f, ray_tmax = 0.f, dist = 0.f, trs = 1.f;
+  bool draws = false;
+  TrackMedium tm;
+  tm.sigma = 1.f; tm.invMax = 1.f; tm.ext = v3(1, 1, 1);
+  tm.g.nx = tm.g.ny = tm.g.nz = 1; tm.g.off = 0; tm.g.iterMax = 1; tm.g.p0 = tm.g.p1 = v3(0, 0, 0);
+  for (;;) {
+    const int n_busy = __popcll(lane_ballot(busy));
+    if (feed.next < feed.end && kWave - n_busy >= kFeedIdle) {
+      const uint32_t mine = feed_take(feed, !busy);
+      if (mine != ~0u) {
+        slot = cur.slot[mine];
+        const float4 o4 = cur.o[mine], d4 = cur.d[mine], h4 = cur.hit[mine];
+        o = v3(o4); d = v3(d4); seg_tmax = d4.w;
+        Hit h;
+        h.t = h4.x; h.prim = __float_as_int(h4.y); h.b1 = h4.z; h.b2 = h4.w;
+        const float4 w4 = P.pend_w[slot];
+        const uint32_t rng_at = __float_as_uint(P.beta_rng[slot].w);
+        tr = v3(w4);
+        medium = __float_as_int(w4.w);
+        MediumRec m;
+        m.type = 0; m.sigmaT = v3(0, 0, 0);
+        if (medium != -1) {   // (asked for before the hit is looked at: one round trip to memory less per refill)
+          load_medium(S, medium, m);
+          track_medium(S, medium, m, tm);
+        }
+        found = h.prim >= 0;
+        med_in = -1; med_out = -1; n = v3(0, 0, 0);
+        bool opaque = false;
+        if (found) {
+          opaque = __float_as_int(S.shade[(size_t)h.prim * kShadeF4 + 6].x) != -1;
+          if (!opaque) {
+            Isect is;
+            load_isect(S, o, d, h, is);
+            med_in = is.med_in; med_out = is.med_out; n = is.n;
+          }
+        }
+        busy = true; looping = false; draws = false;
+        if (opaque) {
+          tr = v3(0, 0, 0);
+          found = false;   // (the ray ends here)
+        } else {
+          ray_tmax = found ? h.t : seg_tmax;
+          if (medium != -1) {
+            if (m.type == 0) {
+              tr = tr * vexp(m.sigmaT * (-ray_tmax));
+            } else {   // ratio tracking (medium.h:53-79), a step per iteration of the loop below
+              rng = rng_at;
+              trs = 1.f; dist = 0.f; iter = tm.g.iterMax;
+              looping = true; draws = true;
+            }
+          }
+        }
+      }
+    } else if (n_busy == 0) {
+      break;
+    }
+    bool want = false;
+    float remaining = 0.f;
+    if (busy && looping) {
+      dist += -fps::log_(rng_uniform(rng)) * tm.invMax / tm.sigma;
+      bool done = dist >= ray_tmax, zero = false;
+      if (!done) {
+        V3 p = o + d * dist;
+        p = (p - tm.g.p0) / tm.ext;
+        trs *= 1.f - het_density(S, tm.g, p) * tm.invMax;
+        if (trs < 0.1f) {
+          const float q = 1.f - trs;
+          if (rng_uniform(rng) < q) { done = true; zero = true; }
+          else trs /= (1.f - q);
+        }
+        if (!done && --iter == 0) done = true;
+      }
+      if (done) {
+        tr = tr * (zero ? v3(0.f, 0.f, 0.f) : v3(trs, trs, trs));
+        looping = false;
+      }
+    }
+    if (busy && !looping) {
+      if (found) {
+        medium = dot(d, n) > 0 ? med_out : med_in;
+        remaining = seg_tmax - ray_tmax;
+        o = o + ray_tmax * d;
+        want = true;
+      }
+      P.pend_w[slot] = f4(tr, (uint32_t)medium);
+      if (draws) P.beta_rng[slot].w = __uint_as_float(rng);
+      busy = false;
+    }
+    stage_push(stage.shadow, sbase, n_next, want, slot, o, -1, d, remaining);
+  }
+  __syncthreads();
+  stage_flush(stage.shadow, sbase, n_next, next);
+}
+
 template <int PHASE>
 __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_vpth(LaunchCtx L, RayQueue cur, RayQueue probe_in, ShadeQueues out,
                                                                     StageArea stage) {
@@ -97,8 +334,11 @@ __global__ __launch_bounds__(kWave, CASTER_SHADE_WAVES) void k_vpth(LaunchCtx L,
           MediumRec med;
           med.g = 0.f; med.type = 0;
           if (rmed != -1) {
+            // the free flight has been sampled by k_vpth_flight: beta and the generator are past it, and the entry's
+            // o.w holds the distance of a scattering event before the surface, if there was one
             load_medium(S, rmed, med);
-            medium_sample(S, rmed, med, ro, rd, rtmax, rng, beta, sampledDist, sampledMedium);
+            sampledMedium = __float_as_int(o4.w) != -1;
+            sampledDist = o4.w;
           }
           if (is_black(beta)) {
             alive = false;

@@ -733,8 +733,11 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
     const bool het = r->vpt_hetero;
     {
       ScopedTimer t(r, st, CASTER_K_SHADE);
-      if (het) hipLaunchKernelGGL(k_vpth<0>, dim3(shade_grid), dim3(kWave), 0, st, L, q, ln.probe, out, ln.stage);
-      else hipLaunchKernelGGL(k_shade_vptq, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
+      if (het) {
+        // the free flights first, in a kernel whose lanes take their next path as soon as their tracking loop ends
+        hipLaunchKernelGGL(k_vpth_flight, dim3(shade_grid * kTrackGridMul), dim3(kWave), 0, st, L, q);
+        hipLaunchKernelGGL(k_vpth<0>, dim3(shade_grid), dim3(kWave), 0, st, L, q, ln.probe, out, ln.stage);
+      } else hipLaunchKernelGGL(k_shade_vptq, dim3(shade_grid), dim3(kWave), 0, st, L, q, out, ln.stage);
     }
     RayQueue* tq[2] = {&ln.shadow, &ln.tr1};
     int tcur = 0;
@@ -747,7 +750,7 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
         ScopedTimer t(r, st, CASTER_K_SHADOW);
         hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, *tq[tcur], aux_for(1));
       }
-      if (het) hipLaunchKernelGGL(k_tr_step<true>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
+      if (het) hipLaunchKernelGGL(k_tr_step_grid, dim3(shade_grid * kTrackGridMul), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
       else hipLaunchKernelGGL(k_tr_step<false>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
       hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, tq[tcur]->count, 0u);
       tcur ^= 1;
