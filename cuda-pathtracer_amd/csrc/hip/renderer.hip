@@ -1415,7 +1415,10 @@ int caster_trace_rays(caster_renderer* r, uint32_t n, const float* origins, cons
                        (uint32_t*)nullptr, 0u, ln.counters + 64, 3u * kWorkShards, r->work_init, 0u);
   };
   reset_work();
-  hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, q, ln.aux);
+  {
+    ScopedTimer timer(r, st, CASTER_K_EXTEND);   // (with profiling on, the launch shows in caster_get_kernel_times)
+    hipLaunchKernelGGL(k_trace<false>, dim3(r->walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, q, ln.aux);
+  }
   reset_work();
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, q.count, 0u);
   HIPCHECK(hipGetLastError());
