@@ -507,3 +507,141 @@ def test_path_tracing_light_tracing_and_bidirectional_path_tracing_estimate_the_
         print(other, "against pt: total", ratio, "median block difference", np.median(rel), "worst", rel.max())
         assert 0.97 < ratio < 1.03, (other, ratio)
         assert np.median(rel) < 0.06 and rel.max() < 0.25, (other, rel)     # (block-wise the difference is noise: light tracing converges slowly)
+
+
+# ------------------------------------------------------------------ what the loader does to a mesh and to the lights
+def _rot(axis, deg):
+    a = np.radians(deg)
+    c, s = np.cos(a), np.sin(a)
+    m = np.eye(4)
+    i, j = (axis + 1) % 3, (axis + 2) % 3
+    m[i, i] = c; m[j, j] = c
+    m[i, j] = -s; m[j, i] = s      # (counter-clockwise about the axis, column vectors)
+    return m
+
+
+def _trs(translate, rotate, scale):
+    """p' = T Rx Ry Rz S p (parsescene.cpp:353-359: glm::rotate multiplies on the right)."""
+    t = np.eye(4); t[:3, 3] = translate
+    s = np.diag(list(scale) + [1.0])
+    return t @ _rot(0, rotate[0]) @ _rot(1, rotate[1]) @ _rot(2, rotate[2]) @ s
+
+
+@pytest.mark.parametrize("how", ["translate-rotate-scale", "transform"])
+def test_a_mesh_lands_where_its_transformation_puts_it(tmp_path, how):
+    """The scene file places a mesh by translate / rotate (degrees about x, then y, then z) / scale, or by a 4 x 4
+    matrix of 16 numbers column after column (parsescene.cpp:21-32, :342-359); normals go through the inverse
+    transpose (mesh.cpp:49-56).  The expected world-space triangles are computed here in float64 with textbook
+    matrices; the oracle's closest hits must be the exhaustive search's, and its shading normals the transformed
+    ones."""
+    rng = np.random.RandomState(11)
+    n_tri = 24
+    centre = rng.rand(n_tri, 1, 3) * 2 - 1
+    tris = centre + (rng.rand(n_tri, 3, 3) - 0.5) * 1.2
+    nrm = face_normals(tris)
+    d = str(tmp_path)
+    write_obj(os.path.join(d, "soup.obj"), tris, nrm)
+    translate, rotate, scale = [0.4, -0.3, 0.7], [25.0, -40.0, 70.0], [1.3, 0.6, 0.9]
+    m = _trs(translate, rotate, scale)
+    entry = {"mesh": "soup.obj", "material": "m"}
+    if how == "transform":
+        entry["transform"] = [float(x) for x in m.T.reshape(-1)]      # column after column
+    else:
+        entry.update({"translate": translate, "rotate": rotate, "scale": scale})
+    doc = {"screen_width": 16, "screen_height": 16, "epsilon": 0.001, "integrator": "pt", "maxDepth": 1,
+           "camera": {"position": [0, 0, 6], "lookat": [0, 0, 0], "up": [0, 1, 0], "fov": 40},
+           "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [0.5, 0.5, 0.5]}],
+           "scene": [entry], "light": []}
+    o = ol.Oracle(write_scene(d, doc))
+    m32 = np.array(entry["transform"], np.float32).reshape(4, 4).T.astype(np.float64) if how == "transform" else m
+    tris32 = tris.astype(np.float32).astype(np.float64)
+    world = np.einsum("ij,tkj->tki", m32[:3, :3], tris32) + m32[:3, 3]
+    normal_matrix = np.linalg.inv(m32[:3, :3]).T
+    world_n = (normal_matrix @ nrm.astype(np.float32).astype(np.float64).T).T
+    world_n /= np.linalg.norm(world_n, axis=1, keepdims=True)
+    n_rays, wrong, hits = 1500, 0, 0
+    for i in range(n_rays):
+        org = (rng.rand(3) * 3.0 - 1.5 + np.array(translate)).astype(np.float32)
+        dr = rng.normal(size=3)
+        dr = (dr / np.linalg.norm(dr)).astype(np.float32)
+        prim, rec = o.trace(org, dr, 1e-3, np.inf)
+        want, want_t = closest_hit_f64(org.astype(np.float64), dr.astype(np.float64), world, [], 1e-3, np.inf)
+        if (prim >= 0) != (want >= 0) or (want >= 0 and abs(rec[0] - want_t) > 3e-4 * (1 + want_t)):
+            wrong += 1
+            continue
+        if want >= 0:
+            hits += 1
+            # one normal per face in the file: the shading normal is the face's, transformed
+            assert abs(abs(float(rec[4:7].astype(np.float64) @ world_n[want])) - 1.0) < 1e-4
+    assert hits > n_rays // 15
+    assert wrong <= n_rays * 0.006, "%d of %d rays disagree with the float64 search" % (wrong, n_rays)
+
+
+def test_lights_are_picked_in_proportion_to_their_power(tmp_path):
+    """Path() picks one emitter per vertex from a distribution over all emissive triangles proportional to the
+    luminance of radiance x area x pi (scene.h:63-80, area.h:32-34, pathtracer.cu:181-194).  With a black floor right
+    under the emitters nothing but the choice decides which emitter a sample's light sample went to: the floor's direct
+    light, emitter by emitter, must be each emitter's own form-factor integral -- which holds whatever the
+    probabilities are, as long as each contribution is divided by the probability actually used -- AND the share of
+    samples whose radiance comes in an emitter's colour must be its share of the power."""
+    d = str(tmp_path)
+    # three emitters of different size and colour, all facing down from y = 2
+    quads = {"r": ([-1.6, -0.2], 0.3, [8, 0, 0]), "g": ([0.0, 0.1], 0.5, [0, 3, 0]), "b": ([1.5, -0.1], 0.2, [0, 0, 20])}
+    lights = []
+    power = {}
+    for name, ((cx, cz), h, rad) in quads.items():
+        q = np.array([[[cx - h, 2.0, cz - h], [cx + h, 2.0, cz - h], [cx + h, 2.0, cz + h]],
+                      [[cx - h, 2.0, cz - h], [cx + h, 2.0, cz + h], [cx - h, 2.0, cz + h]]])
+        write_obj(os.path.join(d, name + ".obj"), q, np.array([[0, -1, 0], [0, -1, 0]], float))
+        lights.append({"mesh": name + ".obj", "material": "m", "radiance": rad})
+        lum = 0.212671 * rad[0] + 0.715160 * rad[1] + 0.072169 * rad[2]
+        power[name] = lum * (2 * h) ** 2 * np.pi
+    floor = np.array([[[-4, 0, 4], [4, 0, 4], [4, 0, -4]], [[-4, 0, 4], [4, 0, -4], [-4, 0, -4]]], float)
+    write_obj(os.path.join(d, "floor.obj"), floor, np.array([[0, 1, 0], [0, 1, 0]], float))
+    doc = {"screen_width": 1, "screen_height": 1, "epsilon": 0.001, "integrator": "pt", "maxDepth": 1,
+           "camera": {"position": [4.2, 1.0, 0.1], "lookat": [0.2, 0, 0.1], "up": [0, 1, 0], "fov": 0.5},
+           "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [1, 1, 1]}],
+           "scene": [{"mesh": "floor.obj", "material": "m"}], "light": lights}
+    o = ol.Oracle(write_scene(d, doc))
+    n = 60000
+    got = np.zeros(3)
+    picks = np.zeros(3)
+    for it in range(1, n + 1):
+        ok, c = o.sample(0, it)
+        assert ok
+        got += c
+        picks += c > 0        # (an emitter's colour is pure: a channel is lit only by its own emitter)
+    got /= n
+    # expected direct light on the white Lambertian floor where the pixel's camera rays land (the pixel is a quarter of
+    # a degree wide, seen at 14 degrees: a patch 0.15 long): sum over emitters of L * (1/pi) * integral cos cos' / r^2 dA,
+    # by midpoint quadrature in float64, averaged over the landing points of 256 of the samples' camera rays
+    landing = []
+    for it in range(1, 257):
+        ray = o.camera_ray(0, 0, it).astype(np.float64)
+        t = -ray[1] / ray[4]
+        landing.append(ray[0:3] + t * ray[3:6])
+    landing = np.array(landing)
+    want = np.zeros(3)
+    visible = {}
+    for ch, (name, ((cx, cz), h, rad)) in enumerate(quads.items()):
+        k = 160
+        xs = cx - h + (np.arange(k) + 0.5) * (2 * h / k)
+        zs = cz - h + (np.arange(k) + 0.5) * (2 * h / k)
+        X, Z = np.meshgrid(xs, zs)
+        ff = 0.0
+        for p in landing:
+            r2 = (X - p[0]) ** 2 + 4.0 + (Z - p[2]) ** 2
+            ff += np.sum(4.0 / (r2 * r2)) * (2 * h / k) ** 2          # cos = cos' = 2 / r
+        ff /= len(landing)
+        want[ch] = rad[ch] * ff / np.pi
+        visible[name] = ff
+    print("direct light per emitter", got, "form factors", want, "picks", picks / n)
+    assert np.allclose(got, want, rtol=0.03), (got, want)
+    # MIS splits an emitter's light between the light sample and the BSDF sample, so a lit channel does not single out
+    # the light-sampling pick exactly; but a pick of emitter k always lights channel k (the floor sees all of every
+    # emitter), hence picks[k] / n >= its share -- and the BSDF sample adds at most the emitter's solid angle / pi
+    share = np.array([power[k] for k in quads]) / sum(power.values())
+    extra = np.array([visible[k] for k in quads]) / np.pi
+    frac = picks / n
+    assert np.all(frac >= share - 0.01), (frac, share)
+    assert np.all(frac <= share + extra + 0.01), (frac, share, extra)
