@@ -645,3 +645,68 @@ def test_lights_are_picked_in_proportion_to_their_power(tmp_path):
     frac = picks / n
     assert np.all(frac >= share - 0.01), (frac, share)
     assert np.all(frac <= share + extra + 0.01), (frac, share, extra)
+
+
+def test_a_textured_floor_in_a_uniform_environment_shows_its_texture(tmp_path):
+    """A Lambertian rectangle whose albedo comes from an image, inside an environment of radiance 1, shows that image:
+    the radiance leaving a flat surface that sees nothing but the environment is its albedo.  What is looked at is what
+    the loader and the lookup make of the file (texture.h:11-24, imageio.cpp:12-52, pathtracer.cu:333-368): the file's
+    first row is the TOP of the picture and v runs upwards, values are sRGB (x^2.2) cut to 8 bits, colour channels in
+    file order, u to the right.  Expected values are computed here from the picture's own formula."""
+    d = str(tmp_path)
+    w, h = 64, 32
+    # a smooth picture, different in every channel and in both directions (in 8-bit sRGB values)
+    col, row = np.meshgrid(np.arange(w), np.arange(h))           # row 0 = top of the picture
+    pic = np.stack([60 + 3 * col, 250 - 6 * row, 40 + 2 * col + 3 * row], -1).astype(np.uint8)
+    with open(os.path.join(d, "pic.ppm"), "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(pic.tobytes())
+    with open(os.path.join(d, "quad.obj"), "w") as f:
+        f.write("v -2 -1 0\nv 2 -1 0\nv 2 1 0\nv -2 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\n"
+                "f 1/1/1 2/2/1 3/3/1\nf 1/1/1 3/3/1 4/4/1\n")
+    write_constant_pfm(os.path.join(d, "env.pfm"), 1.0)
+    W, H = 48, 24
+    doc = {"screen_width": W, "screen_height": H, "integrator": "pt", "maxDepth": 2,
+           "camera": {"position": [0, 0, 6], "lookat": [0, 0, 0], "up": [0, 1, 0], "fov": 15, "filmicTonemap": False},
+           "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "pic.ppm"}],
+           "scene": [{"mesh": "quad.obj", "material": "m"}],
+           "light": [{"infinite": "env.pfm"}]}
+    o = ol.Oracle(write_scene(d, doc))
+    spp = 192
+    img = o.render(1, spp, 8) / spp                               # row 0 = bottom scanline
+
+    def albedo(u, v):
+        """The picture at (u, v), v upwards from the bottom edge, bilinear between texel corners as the lookup does it
+        (texel k spans [k, k + 1) and blends towards k + 1)."""
+        lin = np.floor(((pic[::-1].astype(np.float64) / 255.0) ** 2.2) * 255.0) / 255.0     # bottom row first
+        x, y = u * w, v * h
+        x0, y0 = int(np.floor(x)), int(np.floor(y))
+        fx, fy = x - x0, y - y0
+        x1, y1 = min(x0 + 1, w - 1), min(y0 + 1, h - 1)
+        return ((1 - fy) * ((1 - fx) * lin[y0, x0] + fx * lin[y0, x1]) + fy * ((1 - fx) * lin[y1, x0] + fx * lin[y1, x1]))
+
+    checked = 0
+    worst = 0.0
+    for by in range(0, H, 4):
+        for bx in range(0, W, 4):
+            want, inside = np.zeros(3), True
+            for y in range(by, by + 4):
+                for x in range(bx, bx + 4):
+                    ray = o.camera_ray(x, y, 1).astype(np.float64)     # (one of the pixel's jittered rays: within the pixel)
+                    t = -ray[2] / ray[5]
+                    px, py = ray[0] + t * ray[3], ray[1] + t * ray[4]
+                    u, v = (px + 2) / 4, (py + 1) / 2
+                    if not (0.03 < u < 0.97 and 0.03 < v < 0.97):
+                        inside = False
+                        break
+                    want += albedo(u, v) / 16
+                if not inside:
+                    break
+            if not inside:
+                continue
+            got = img[by:by + 4, bx:bx + 4].reshape(-1, 3).mean(0)
+            worst = max(worst, float(np.max(np.abs(got - want) / np.maximum(want, 0.02))))
+            checked += 1
+    print("blocks", checked, "worst relative difference", worst)
+    assert checked >= 12
+    assert worst < 0.04
