@@ -69,6 +69,60 @@ def test_full_size_config(caster, tmp_path, key):
     np.testing.assert_array_equal(band_gpu, band_cpu)
 
 
+FULL = {
+    "C2_knot_1024x256spp": ("knot_pt", 1024, 1024, 8, 256, 100_000),
+    "C3_stairs_1080p_1024spp": ("stairs_pt", 1920, 1080, 8, 1024, 300_000),
+    "C4_cornell_vpt_1024_1024spp": ("cornell_vpt", 1024, 1024, 16, 1024, 20),
+    "C5_car_1080p_4096spp": ("car_pt", 1920, 1080, 8, 4096, 1_000_000),
+}
+
+
+@pytest.mark.parametrize("key", sorted(FULL))
+def test_config_at_its_full_sample_count(caster, tmp_path, key):
+    """A benchmark configuration at its whole size (for C5: 1.37 M triangles, 1920x1080, 4096 samples per pixel, 8.49 G
+    samples), which no oracle run can cover, through what must hold at any size: the film does not depend on how the
+    iterations are cut into calls and batches (a sample is a function of its pixel and iteration, the film a sum in
+    iteration order), every sample is accounted for, and the two halves of the iterations -- independent estimates of
+    the same image -- agree as Monte Carlo estimates of that many samples do."""
+    name, w, h, depth, spp, min_prims = FULL[key]
+    path = gen_scenes.generate(str(tmp_path / "full"), name, 1.0, w, h, depth)
+    sc = caster.Scene(path)
+    assert sc.info.n_prims > min_prims and (sc.width, sc.height, sc.info.max_depth) == (w, h, depth)
+    r = caster.Renderer(sc, 0, 0)
+    r.render(1, spp, True)
+    whole = r.read_film(2)
+    st = r.stats()
+    assert st["samples"] == w * h * spp and st["stack_overflow"] == 0
+    # (samples that are not numbers are dropped and counted, as the reference drops them: its microfacet formulas
+    # produce them -- a percent of the staircase's samples, with its rough conductors and rough glass)
+    print(key, "invalid samples: %.2e of all" % (st["invalid"] / st["samples"]))
+    assert st["invalid"] < 0.02 * st["samples"]
+    assert st["rays"][0] >= st["samples"] and st["rays"][1] + st["rays"][3] > 0   # (shadow rays, or their Tr() segments)
+    # the same iterations in four uneven calls (batches of other sizes, other streams)
+    r.reset_stats()
+    first = 1
+    halves = []
+    for k, n in enumerate((spp // 4 - 24, 1, spp // 4 + 23, spp // 2)):
+        r.render(first, n, k == 0)
+        first += n
+        if first == spp // 2 + 1:
+            halves.append(r.read_film(2))
+    pieces = r.read_film(2)
+    assert r.stats()["samples"] == w * h * spp
+    r.close()
+    np.testing.assert_array_equal(pieces, whole)
+    # the first half of the iterations against the second
+    a = halves[0] / (spp // 2)
+    b = (whole - halves[0]) / (spp // 2)
+    # (the reference clamps nothing: a single sample of 1e12 through a near-singular density is a legitimate value, so
+    # the two halves are compared by their medians and by the spread of the per-pixel differences, not by their means)
+    assert np.isfinite(whole).all() and np.median(whole) > 0
+    assert abs(np.median(a) - np.median(b)) <= 0.02 * np.median(a)
+    rel = np.abs(a - b) / (np.abs(b) + 1e-2)
+    print(key, "medians", float(np.median(a)), float(np.median(b)), "90th percentile of the relative difference", float(np.percentile(rel, 90)))
+    assert np.percentile(rel, 90) <= 0.6 * np.sqrt(128.0 / (spp // 2))
+
+
 @pytest.mark.parametrize("integrator", ["lt", "bdpt"])
 def test_splatting_integrators_at_full_size(caster, tmp_path, integrator):
     """Light tracing and BDPT on the staircase scene at 1920x1080: the oracle cannot render the frame,
