@@ -92,3 +92,58 @@ def test_path_tracing_light_tracing_and_bidirectional_path_tracing_estimate_the_
         print(other, "against pt: total", ratio, "median block difference", np.median(rel), "worst", rel.max())
         assert 0.98 < ratio < 1.02, (other, ratio)
         assert np.median(rel) < 0.06 and rel.max() < 0.25, (other, rel)   # (block-wise the difference is noise)
+
+
+@pytest.mark.parametrize("how", ["translate-rotate-scale", "transform"])
+def test_a_mesh_lands_where_its_transformation_puts_it(caster, tmp_path, how):
+    """The traversal kernel's closest hits in a scene whose mesh is placed by a transformation, against the exhaustive
+    float64 search over the triangles transformed with textbook matrices (the oracle's test of the same name)."""
+    path, world, world_n, centre = ind.transformed_mesh_scene(str(tmp_path), how)
+    sc = caster.Scene(path)
+    r = caster.Renderer(sc, 0, 8)      # (the hook traces as many rays as the renderer has path slots: 8 x 16 x 16)
+    org, dr = ind.rays_about(centre, 1500)
+    prim, t = r.trace_rays(org, dr, np.full(len(org), np.inf, np.float32))
+    rec = r.eval_function("hit_record", np.concatenate([org, dr, t[:, None], prim.view(np.float32)[:, None]], 1))
+    r.close()
+    wrong, hits = 0, 0
+    for i in range(len(org)):
+        want, want_t = ind.closest_hit_f64(org[i].astype(np.float64), dr[i].astype(np.float64), world, [], 1e-3, np.inf)
+        if (prim[i] >= 0) != (want >= 0) or (want >= 0 and abs(t[i] - want_t) > 3e-4 * (1 + want_t)):
+            wrong += 1
+            continue
+        if want >= 0:
+            hits += 1
+            assert abs(abs(float(rec[i, 3:6].astype(np.float64) @ world_n[want])) - 1.0) < 1e-4
+    assert hits > len(org) // 15
+    assert wrong <= len(org) * 0.006, "%d of %d rays disagree with the float64 search" % (wrong, len(org))
+
+
+def test_each_of_three_emitters_lights_the_floor_by_its_own_form_factor(caster, tmp_path):
+    """(The oracle's test_lights_are_picked_in_proportion_to_their_power, without the count of picks: the film of the
+    one-pixel image after 262 144 iterations, channel by channel, against each emitter's form-factor integral.)"""
+    path, quads, share = ind.three_emitters_scene(str(tmp_path))
+    sc = caster.Scene(path)
+    r = caster.Renderer(sc, 0, 4096)
+    n = 1 << 18
+    r.render(1, n, True)
+    got = r.read_film(0).reshape(3)
+    cam = r.eval_function("camera_ray", np.array([[0, 0, it] for it in range(1, 257)], np.int32).view(np.float32))
+    r.close()
+    want, _ = ind.three_emitters_expected(quads, ind.floor_landing(cam))
+    print("direct light per emitter", got, "form factors", want)
+    assert np.allclose(got, want, rtol=0.02), (got, want)
+
+
+def test_a_textured_floor_in_a_uniform_environment_shows_its_texture(caster, tmp_path):
+    path, size, albedo = ind.textured_floor_scene(str(tmp_path))
+    img = render_mean(caster, path, 1024)
+    sc = caster.Scene(path)
+    r = caster.Renderer(sc, 0, 1)
+    W, H = size
+    xy = np.array([[x, y, 1] for y in range(H) for x in range(W)], np.int32)
+    cam = r.eval_function("camera_ray", xy.view(np.float32)).reshape(H, W, 6)
+    r.close()
+    checked, worst = ind.textured_floor_worst_block(img, size, albedo, lambda x, y: cam[y, x])
+    print("blocks", checked, "worst relative difference", worst)
+    assert checked >= 12
+    assert worst < 0.03

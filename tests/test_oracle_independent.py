@@ -527,19 +527,14 @@ def _trs(translate, rotate, scale):
     return t @ _rot(0, rotate[0]) @ _rot(1, rotate[1]) @ _rot(2, rotate[2]) @ s
 
 
-@pytest.mark.parametrize("how", ["translate-rotate-scale", "transform"])
-def test_a_mesh_lands_where_its_transformation_puts_it(tmp_path, how):
-    """The scene file places a mesh by translate / rotate (degrees about x, then y, then z) / scale, or by a 4 x 4
-    matrix of 16 numbers column after column (parsescene.cpp:21-32, :342-359); normals go through the inverse
-    transpose (mesh.cpp:49-56).  The expected world-space triangles are computed here in float64 with textbook
-    matrices; the oracle's closest hits must be the exhaustive search's, and its shading normals the transformed
-    ones."""
+def transformed_mesh_scene(d, how):
+    """A soup of triangles placed by translate / rotate / scale or by the same transformation as 16 numbers: the scene
+    file, the world-space triangles and face normals computed here in float64 with textbook matrices, and where to aim."""
     rng = np.random.RandomState(11)
     n_tri = 24
     centre = rng.rand(n_tri, 1, 3) * 2 - 1
     tris = centre + (rng.rand(n_tri, 3, 3) - 0.5) * 1.2
     nrm = face_normals(tris)
-    d = str(tmp_path)
     write_obj(os.path.join(d, "soup.obj"), tris, nrm)
     translate, rotate, scale = [0.4, -0.3, 0.7], [25.0, -40.0, 70.0], [1.3, 0.6, 0.9]
     m = _trs(translate, rotate, scale)
@@ -552,20 +547,36 @@ def test_a_mesh_lands_where_its_transformation_puts_it(tmp_path, how):
            "camera": {"position": [0, 0, 6], "lookat": [0, 0, 0], "up": [0, 1, 0], "fov": 40},
            "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [0.5, 0.5, 0.5]}],
            "scene": [entry], "light": []}
-    o = ol.Oracle(write_scene(d, doc))
     m32 = np.array(entry["transform"], np.float32).reshape(4, 4).T.astype(np.float64) if how == "transform" else m
     tris32 = tris.astype(np.float32).astype(np.float64)
     world = np.einsum("ij,tkj->tki", m32[:3, :3], tris32) + m32[:3, 3]
     normal_matrix = np.linalg.inv(m32[:3, :3]).T
     world_n = (normal_matrix @ nrm.astype(np.float32).astype(np.float64).T).T
     world_n /= np.linalg.norm(world_n, axis=1, keepdims=True)
-    n_rays, wrong, hits = 1500, 0, 0
-    for i in range(n_rays):
-        org = (rng.rand(3) * 3.0 - 1.5 + np.array(translate)).astype(np.float32)
-        dr = rng.normal(size=3)
-        dr = (dr / np.linalg.norm(dr)).astype(np.float32)
-        prim, rec = o.trace(org, dr, 1e-3, np.inf)
-        want, want_t = closest_hit_f64(org.astype(np.float64), dr.astype(np.float64), world, [], 1e-3, np.inf)
+    return write_scene(d, doc), world, world_n, np.array(translate)
+
+
+def rays_about(centre, n, seed=12):
+    rng = np.random.RandomState(seed)
+    org = (rng.rand(n, 3) * 3.0 - 1.5 + centre).astype(np.float32)
+    dr = rng.normal(size=(n, 3))
+    dr = (dr / np.linalg.norm(dr, axis=1, keepdims=True)).astype(np.float32)
+    return org, dr
+
+
+@pytest.mark.parametrize("how", ["translate-rotate-scale", "transform"])
+def test_a_mesh_lands_where_its_transformation_puts_it(tmp_path, how):
+    """The scene file places a mesh by translate / rotate (degrees about x, then y, then z) / scale, or by a 4 x 4
+    matrix of 16 numbers column after column (parsescene.cpp:21-32, :342-359); normals go through the inverse
+    transpose (mesh.cpp:49-56).  The oracle's closest hits must be those of the exhaustive float64 search over the
+    triangles transformed here, and its shading normals the transformed face normals."""
+    path, world, world_n, centre = transformed_mesh_scene(str(tmp_path), how)
+    o = ol.Oracle(path)
+    org, dr = rays_about(centre, 1500)
+    wrong, hits = 0, 0
+    for a, b in zip(org, dr):
+        prim, rec = o.trace(a, b, 1e-3, np.inf)
+        want, want_t = closest_hit_f64(a.astype(np.float64), b.astype(np.float64), world, [], 1e-3, np.inf)
         if (prim >= 0) != (want >= 0) or (want >= 0 and abs(rec[0] - want_t) > 3e-4 * (1 + want_t)):
             wrong += 1
             continue
@@ -573,19 +584,14 @@ def test_a_mesh_lands_where_its_transformation_puts_it(tmp_path, how):
             hits += 1
             # one normal per face in the file: the shading normal is the face's, transformed
             assert abs(abs(float(rec[4:7].astype(np.float64) @ world_n[want])) - 1.0) < 1e-4
-    assert hits > n_rays // 15
-    assert wrong <= n_rays * 0.006, "%d of %d rays disagree with the float64 search" % (wrong, n_rays)
+    assert hits > len(org) // 15
+    assert wrong <= len(org) * 0.006, "%d of %d rays disagree with the float64 search" % (wrong, len(org))
 
 
-def test_lights_are_picked_in_proportion_to_their_power(tmp_path):
-    """Path() picks one emitter per vertex from a distribution over all emissive triangles proportional to the
-    luminance of radiance x area x pi (scene.h:63-80, area.h:32-34, pathtracer.cu:181-194).  With a black floor right
-    under the emitters nothing but the choice decides which emitter a sample's light sample went to: the floor's direct
-    light, emitter by emitter, must be each emitter's own form-factor integral -- which holds whatever the
-    probabilities are, as long as each contribution is divided by the probability actually used -- AND the share of
-    samples whose radiance comes in an emitter's colour must be its share of the power."""
-    d = str(tmp_path)
-    # three emitters of different size and colour, all facing down from y = 2
+def three_emitters_scene(d):
+    """Three one-sided emitters of different size and colour over a white Lambertian floor, looked at through one
+    narrow pixel: the scene file, the emitters, and each emitter's share of the power (luminance of radiance x area x
+    pi, scene.h:63-80, area.h:32-34)."""
     quads = {"r": ([-1.6, -0.2], 0.3, [8, 0, 0]), "g": ([0.0, 0.1], 0.5, [0, 3, 0]), "b": ([1.5, -0.1], 0.2, [0, 0, 20])}
     lights = []
     power = {}
@@ -602,27 +608,15 @@ def test_lights_are_picked_in_proportion_to_their_power(tmp_path):
            "camera": {"position": [4.2, 1.0, 0.1], "lookat": [0.2, 0, 0.1], "up": [0, 1, 0], "fov": 0.5},
            "material": [{"name": "m", "bsdf": "lambertian", "diffuse": [1, 1, 1]}],
            "scene": [{"mesh": "floor.obj", "material": "m"}], "light": lights}
-    o = ol.Oracle(write_scene(d, doc))
-    n = 60000
-    got = np.zeros(3)
-    picks = np.zeros(3)
-    for it in range(1, n + 1):
-        ok, c = o.sample(0, it)
-        assert ok
-        got += c
-        picks += c > 0        # (an emitter's colour is pure: a channel is lit only by its own emitter)
-    got /= n
-    # expected direct light on the white Lambertian floor where the pixel's camera rays land (the pixel is a quarter of
-    # a degree wide, seen at 14 degrees: a patch 0.15 long): sum over emitters of L * (1/pi) * integral cos cos' / r^2 dA,
-    # by midpoint quadrature in float64, averaged over the landing points of 256 of the samples' camera rays
-    landing = []
-    for it in range(1, 257):
-        ray = o.camera_ray(0, 0, it).astype(np.float64)
-        t = -ray[1] / ray[4]
-        landing.append(ray[0:3] + t * ray[3:6])
-    landing = np.array(landing)
+    share = np.array([power[k] for k in quads]) / sum(power.values())
+    return write_scene(d, doc), quads, share
+
+
+def three_emitters_expected(quads, landing):
+    """Direct light on the white floor at the points `landing`, emitter by emitter: L * (1/pi) * integral of
+    cos cos' / r^2 dA by midpoint quadrature in float64 (and the bare integrals)."""
     want = np.zeros(3)
-    visible = {}
+    visible = np.zeros(3)
     for ch, (name, ((cx, cz), h, rad)) in enumerate(quads.items()):
         k = 160
         xs = cx - h + (np.arange(k) + 0.5) * (2 * h / k)
@@ -634,26 +628,52 @@ def test_lights_are_picked_in_proportion_to_their_power(tmp_path):
             ff += np.sum(4.0 / (r2 * r2)) * (2 * h / k) ** 2          # cos = cos' = 2 / r
         ff /= len(landing)
         want[ch] = rad[ch] * ff / np.pi
-        visible[name] = ff
+        visible[ch] = ff
+    return want, visible
+
+
+def floor_landing(camera_rays):
+    """Where camera rays (origin.xyz | dir.xyz rows) meet the plane y = 0."""
+    rays = np.asarray(camera_rays, np.float64).reshape(-1, 6)
+    t = -rays[:, 1] / rays[:, 4]
+    return rays[:, 0:3] + t[:, None] * rays[:, 3:6]
+
+
+def test_lights_are_picked_in_proportion_to_their_power(tmp_path):
+    """Path() picks one emitter per vertex from a distribution over all emissive triangles proportional to their
+    power (pathtracer.cu:181-194).  The floor's direct light, emitter by emitter (each has a colour channel of its own),
+    must be that emitter's form-factor integral -- which holds whatever the probabilities are, as long as each
+    contribution is divided by the probability actually used -- AND the share of samples lit in an emitter's channel
+    must be its share of the power, give or take what the BSDF sample adds."""
+    path, quads, share = three_emitters_scene(str(tmp_path))
+    o = ol.Oracle(path)
+    n = 60000
+    got = np.zeros(3)
+    picks = np.zeros(3)
+    for it in range(1, n + 1):
+        ok, c = o.sample(0, it)
+        assert ok
+        got += c
+        picks += c > 0        # (an emitter's colour is pure: a channel is lit only by its own emitter)
+    got /= n
+    # (the pixel is a quarter of a degree wide, seen at 14 degrees: a patch 0.15 long; the expectation is averaged over
+    # the landing points of 256 of the samples' camera rays)
+    landing = floor_landing([o.camera_ray(0, 0, it) for it in range(1, 257)])
+    want, visible = three_emitters_expected(quads, landing)
     print("direct light per emitter", got, "form factors", want, "picks", picks / n)
     assert np.allclose(got, want, rtol=0.03), (got, want)
     # MIS splits an emitter's light between the light sample and the BSDF sample, so a lit channel does not single out
     # the light-sampling pick exactly; but a pick of emitter k always lights channel k (the floor sees all of every
     # emitter), hence picks[k] / n >= its share -- and the BSDF sample adds at most the emitter's solid angle / pi
-    share = np.array([power[k] for k in quads]) / sum(power.values())
-    extra = np.array([visible[k] for k in quads]) / np.pi
     frac = picks / n
     assert np.all(frac >= share - 0.01), (frac, share)
-    assert np.all(frac <= share + extra + 0.01), (frac, share, extra)
+    assert np.all(frac <= share + visible / np.pi + 0.01), (frac, share, visible)
 
 
-def test_a_textured_floor_in_a_uniform_environment_shows_its_texture(tmp_path):
-    """A Lambertian rectangle whose albedo comes from an image, inside an environment of radiance 1, shows that image:
-    the radiance leaving a flat surface that sees nothing but the environment is its albedo.  What is looked at is what
-    the loader and the lookup make of the file (texture.h:11-24, imageio.cpp:12-52, pathtracer.cu:333-368): the file's
-    first row is the TOP of the picture and v runs upwards, values are sRGB (x^2.2) cut to 8 bits, colour channels in
-    file order, u to the right.  Expected values are computed here from the picture's own formula."""
-    d = str(tmp_path)
+def textured_floor_scene(d):
+    """A Lambertian rectangle (4 x 2 in the plane z = 0, uv from its lower left corner) whose albedo comes from a
+    picture, inside an environment of radiance 1: the scene file, the image size, and the albedo as a function of
+    (u, v) computed from the picture's own formula."""
     w, h = 64, 32
     # a smooth picture, different in every channel and in both directions (in 8-bit sRGB values)
     col, row = np.meshgrid(np.arange(w), np.arange(h))           # row 0 = top of the picture
@@ -671,28 +691,31 @@ def test_a_textured_floor_in_a_uniform_environment_shows_its_texture(tmp_path):
            "material": [{"name": "m", "bsdf": "lambertian", "diffuse": "pic.ppm"}],
            "scene": [{"mesh": "quad.obj", "material": "m"}],
            "light": [{"infinite": "env.pfm"}]}
-    o = ol.Oracle(write_scene(d, doc))
-    spp = 192
-    img = o.render(1, spp, 8) / spp                               # row 0 = bottom scanline
+    lin = np.floor(((pic[::-1].astype(np.float64) / 255.0) ** 2.2) * 255.0) / 255.0     # bottom row first
 
     def albedo(u, v):
         """The picture at (u, v), v upwards from the bottom edge, bilinear between texel corners as the lookup does it
         (texel k spans [k, k + 1) and blends towards k + 1)."""
-        lin = np.floor(((pic[::-1].astype(np.float64) / 255.0) ** 2.2) * 255.0) / 255.0     # bottom row first
         x, y = u * w, v * h
         x0, y0 = int(np.floor(x)), int(np.floor(y))
         fx, fy = x - x0, y - y0
         x1, y1 = min(x0 + 1, w - 1), min(y0 + 1, h - 1)
         return ((1 - fy) * ((1 - fx) * lin[y0, x0] + fx * lin[y0, x1]) + fy * ((1 - fx) * lin[y1, x0] + fx * lin[y1, x1]))
 
-    checked = 0
-    worst = 0.0
+    return write_scene(d, doc), (W, H), albedo
+
+
+def textured_floor_worst_block(img, size, albedo, camera_ray):
+    """Largest relative difference between 4 x 4-pixel block means of `img` (row 0 = bottom) and the albedo where the
+    pixels' camera rays (camera_ray(x, y) -> origin.xyz | dir.xyz) meet the rectangle; (blocks checked, worst)."""
+    W, H = size
+    checked, worst = 0, 0.0
     for by in range(0, H, 4):
         for bx in range(0, W, 4):
             want, inside = np.zeros(3), True
             for y in range(by, by + 4):
                 for x in range(bx, bx + 4):
-                    ray = o.camera_ray(x, y, 1).astype(np.float64)     # (one of the pixel's jittered rays: within the pixel)
+                    ray = np.asarray(camera_ray(x, y), np.float64)     # (one of the pixel's jittered rays: within the pixel)
                     t = -ray[2] / ray[5]
                     px, py = ray[0] + t * ray[3], ray[1] + t * ray[4]
                     u, v = (px + 2) / 4, (py + 1) / 2
@@ -707,6 +730,20 @@ def test_a_textured_floor_in_a_uniform_environment_shows_its_texture(tmp_path):
             got = img[by:by + 4, bx:bx + 4].reshape(-1, 3).mean(0)
             worst = max(worst, float(np.max(np.abs(got - want) / np.maximum(want, 0.02))))
             checked += 1
+    return checked, worst
+
+
+def test_a_textured_floor_in_a_uniform_environment_shows_its_texture(tmp_path):
+    """A Lambertian rectangle whose albedo comes from an image, inside an environment of radiance 1, shows that image:
+    the radiance leaving a flat surface that sees nothing but the environment is its albedo.  What is looked at is what
+    the loader and the lookup make of the file (texture.h:11-24, imageio.cpp:12-52, pathtracer.cu:333-368): the file's
+    first row is the TOP of the picture and v runs upwards, values are sRGB (x^2.2) cut to 8 bits, colour channels in
+    file order, u to the right."""
+    path, size, albedo = textured_floor_scene(str(tmp_path))
+    o = ol.Oracle(path)
+    spp = 192
+    img = o.render(1, spp, 8) / spp                               # row 0 = bottom scanline
+    checked, worst = textured_floor_worst_block(img, size, albedo, lambda x, y: o.camera_ray(x, y, 1))
     print("blocks", checked, "worst relative difference", worst)
     assert checked >= 12
     assert worst < 0.04
