@@ -271,11 +271,33 @@ __device__ __noinline__ void bdpt_vertex_fr(const DevScene& S, bool use_medium, 
 }
 
 // Connect() (:1706-1909) for the camera prefix of s vertices and the light prefix of t.
+// The shadow ray of a join, when it is not walked where the join is evaluated.
+struct JoinRay {
+  bool want;
+  V3 o, d;
+  float tmax;
+  int medium;
+};
+#ifdef CASTER_BDPT_DIAG_NO_TR   // diagnosis builds only: every join sees its other end
+#define transmittance(...) v3(1.f, 1.f, 1.f)
+#endif
+// QUEUED: the transmittance between the joined vertices is not walked here; the join comes back with transmittance
+// one and its shadow ray in `ray` (which is wanted wherever the reference calls Tr(), whatever the join turns out to
+// be worth afterwards: the ray statistics are the reference's), and the caller sends the ray through the traversal
+// kernel and multiplies afterwards.
+template <bool QUEUED>
 __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const BdptStore& V, uint32_t g, int s, int t, int& raster,
-                           uint32_t& rng, uint32_t& n_tr) {
+                           uint32_t& rng, uint32_t& n_tr, JoinRay& ray) {
   const V3 zero = v3(0.f, 0.f, 0.f);
   const int LB = kBdptPathVerts;
   const float eps = S.epsilon;
+  auto visibility = [&](V3 o, V3 d, float tmax, int medium) -> V3 {
+    if (QUEUED) {
+      ray.want = true; ray.o = o; ray.d = d; ray.tmax = tmax; ray.medium = medium;
+      return v3(1.f, 1.f, 1.f);
+    }
+    return transmittance(S, o, d, eps, tmax, medium, st, stats, n_tr, rng);
+  };
   if (t == 0) {  // the camera path hit an emitter (:1710-1735)
     BVert cur;
     bv_load(V, g, s - 1, cur);
@@ -320,7 +342,7 @@ __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const Bdp
     V3 lightPos = cur.pos + (stmax + eps) * sdir;
     if (is_black(radiance)) return zero;
     if (!isMedium && cur.delta) return zero;
-    V3 tr = transmittance(S, cur.pos, sdir, eps, stmax, cur.medium, st, stats, n_tr, rng);
+    V3 tr = visibility(cur.pos, sdir, stmax, cur.medium);
     if (is_black(tr)) return zero;
     V3 fr;
     float nextPdf, pdf;
@@ -349,7 +371,7 @@ __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const Bdp
     sample_camera(S, cur.pos, sdir, stmax, we, cameraPdf, raster);
     if (cameraPdf == 0) return zero;
     if (!isMedium && cur.delta) return zero;
-    V3 tr = transmittance(S, cur.pos, sdir, eps, stmax, cur.medium, st, stats, n_tr, rng);
+    V3 tr = visibility(cur.pos, sdir, stmax, cur.medium);
     if (is_black(tr)) return zero;
     V3 fr;
     float nextPdf, pdf, costheta = fabsf(dot(sdir, cur.n));
@@ -382,7 +404,7 @@ __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const Bdp
   float stmax = length(dir) - eps;
   if (!c1Med && c1.delta) return zero;
   if (!l1Med && l1.delta) return zero;
-  V3 tr = transmittance(S, c1.pos, c1Tol1, eps, stmax, c1.medium, st, stats, n_tr, rng);
+  V3 tr = visibility(c1.pos, c1Tol1, stmax, c1.medium);
   if (is_black(tr)) return zero;
   float cos1 = l1Med ? 1.f : fabsf(dot(l1Toc1, l1.n));
   float cos2 = c1Med ? 1.f : fabsf(dot(c1Tol1, c1.n));
@@ -399,6 +421,51 @@ __device__ V3 bdpt_connect(const DevScene& S, Stack& st, Stats* stats, const Bdp
   float c2_rev = convert_pdf(c2Pdf, c1.pos, c2_pos, c2_n);
   float mis = bdpt_mis(V, g, s, t, c1_rev, c2_rev, l1_rev, l2_rev, 0.f);
   return mis * Lr;
+}
+
+#ifdef CASTER_BDPT_DIAG_NO_TR
+#undef transmittance
+#endif
+
+// ---- joins whose shadow rays go through the traversal kernel ---------------------------------------------------------
+// On a scene of a million triangles nine tenths of the one-kernel integrator's time is tree walks, every lane in a loop
+// of its own, and six tenths of it the joins' shadow rays.  Where Tr() draws no random numbers (no density grid) a
+// join's contribution is its value without the transmittance times the transmittance, so the wavefront that evaluates
+// a join only writes down the value and the ray; the rays of a launch are advanced a Tr() segment per pass of the
+// traversal kernel (k_tr_step / k_tr_finish, as the volumetric integrator's shadow rays are) and k_bdpt_resolve
+// splats value x transmittance.  Join slot i is entry i of the queue.
+//
+// Slots are handed out a round at a time: when its 64 samples have been walked a wavefront knows how many joins they
+// have that can want a shadow ray (all but the emitter hits) and takes that many slots with one compare-and-swap; join
+// j of the round then owns slot first + j, and a join that turns out to want no ray fills its slot with a ray that
+// is over before it starts.  A round that finds the queue too full is put on a list instead and evaluated afterwards by
+// the kernel that walks its shadow rays in place -- so no launch depends on a bound on the joins of a sample, and the
+// kernel that queues carries no tree walk for its joins (with one it ran a third slower: 139 against 181 Msamples/s).
+struct BdptJoins {
+  RayQueue q;            // the rays, in slot order (q.slot[i] == i)
+  float4* val;           // slot -> value without transmittance | raster index
+  uint32_t cap;          // slots
+  uint32_t* unused;      // slots of this launch filled with a ray that is over before it starts
+  uint32_t* deferred;    // first samples of the rounds left to the in-place kernel
+  uint32_t* n_deferred;
+};
+// After a launch of k_bdpt<true>: the slots it handed out; the empty ones come off the count of transmittance segments
+// that the first traversal pass is about to add.
+__global__ void k_join_count(uint32_t* count, uint32_t cap, uint32_t* n_out, uint32_t* unused, Stats* stats) {
+  const uint32_t n = *count < cap ? *count : cap;   // (rounds that found no room left the counter beyond the queue)
+  *count = n;
+  *n_out = n;
+  stats->rays[3] -= (unsigned long long)*unused;
+  *unused = 0u;
+}
+__global__ __launch_bounds__(256) void k_bdpt_resolve(LaunchCtx L, BdptJoins J, const uint32_t* n_ptr, float* acc) {
+  const uint32_t n = *n_ptr;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 v = J.val[i];
+    const V3 Lc = v3(v) * v3(L.P.pend_w[i]);
+    if (has_inf(Lc) || has_nan(Lc) || is_black(Lc)) continue;
+    splat(L.S, acc, __float_as_int(v.w), Lc);
+  }
 }
 
 // minstd_rand state after k more draws: x * 48271^k mod (2^31 - 1)
@@ -426,9 +493,21 @@ __device__ inline uint32_t rng_skip(uint32_t x, uint32_t k) {
 // reached with a skip-ahead of the generator.  With a density grid in the scene the transmittance
 // of a join draws a data-dependent number of values, and every lane evaluates its own sample's
 // joins in order.
-__global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter, uint32_t n_iter, float* acc,
-                                                WalkAux aux, BdptStore V) {
+#ifndef CASTER_BDPT_WAVES
+// Wavefronts per SIMD the register budget is held to.  Left to itself the kernel takes 189 registers (two wavefronts
+// per SIMD) and waits for memory most of the time; held to 96 it spills 287 values to scratch and is still half as
+// fast again, because five wavefronts cover one another's waits (benchmark scene, 1080p: 65 Msamples/s at 189
+// registers, 83 at 168, 99 at 128, 105 at 96, 92 at 80).
+#define CASTER_BDPT_WAVES 5
+#endif
+// Samples [begin, end) of the batch (multiples of the wavefront size), or -- `rounds` given -- the rounds of 64 samples
+// that start at the *n_rounds sample indices listed there.  QUEUED: see BdptJoins.
+template <bool QUEUED>
+__global__ __launch_bounds__(kWave, CASTER_BDPT_WAVES) void k_bdpt(LaunchCtx L, uint32_t first_iter, uint32_t n_iter, uint32_t begin,
+                                                                    uint32_t end, float* acc, WalkAux aux, BdptStore V, BdptJoins J,
+                                                                    const uint32_t* rounds, const uint32_t* n_rounds) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
+  __shared__ int s_pix[kWave];
   __shared__ uint32_t s_end[kWave + 1];  // joins of the samples of lanes < i
   __shared__ uint32_t s_rng[kWave];
   __shared__ int s_nl[kWave], s_nc[kWave];
@@ -439,8 +518,11 @@ __global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter
   const uint32_t g0 = blockIdx.x * kWave, g = g0 + lane;
   const int LB = kBdptPathVerts;
   uint32_t n_ext = 0, n_tr = 0;
-  uint32_t total = (uint32_t)S.slots_per_iter * n_iter;  // a multiple of the wavefront size: the loop is wave-uniform
-  for (uint32_t idx = g; idx < total; idx += gridDim.x * kWave) {
+  uint32_t n_dummy = 0;
+  const uint32_t n_round = rounds ? *n_rounds : (end - begin) / kWave;
+  for (uint32_t round = blockIdx.x; round < n_round; round += gridDim.x) {   // (the loop is wave-uniform)
+    const uint32_t idx0 = rounds ? rounds[round] : begin + round * kWave, idx = idx0 + lane;
+    const uint32_t n_ext_before = n_ext;
     uint32_t k, local;
     batch_slot_split(S, idx, n_iter, k, local);
     uint32_t px, py;
@@ -500,7 +582,8 @@ __global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter
         for (int t = 0; t <= nLight; ++t) {
           if (s == 1 && t <= 1) continue;
           int raster = -1;
-          V3 Lc = bdpt_connect(S, st, L.stats, V, g, s, t, raster, rng, n_tr);
+          JoinRay unused;
+          V3 Lc = bdpt_connect<false>(S, st, L.stats, V, g, s, t, raster, rng, n_tr, unused);
           if (has_inf(Lc) || has_nan(Lc) || is_black(Lc)) continue;
           if (s == 1) splat(S, acc, raster, Lc);
           else own = own + Lc;
@@ -517,7 +600,41 @@ __global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter
     s_nl[lane] = nLight;
     s_nc[lane] = nCamera;
     s_own[lane][0] = 0.f; s_own[lane][1] = 0.f; s_own[lane][2] = 0.f;
+    s_pix[lane] = (int)pixel;
+    uint32_t slot_next = 0;   // QUEUED: the slot of the first join of the kind under way
+    if (QUEUED) {
+      const int cs = nCamera - 1 > 0 ? nCamera - 1 : 0, lt = nLight - 1 > 0 ? nLight - 1 : 0;
+      uint32_t want = (uint32_t)((nLight >= 1 ? cs : 0) + (nCamera >= 1 ? lt : 0) + cs * lt);
+      for (int off = 32; off > 0; off >>= 1) want += (uint32_t)__shfl_xor((int)want, off, kWave);
+      // (one atomic add per round, never a compare-and-swap loop: some thousand wavefronts retrying on one address
+      // made the launch six times longer)
+      uint32_t first = 0u;
+      if (want != 0 && lane == 0) first = atomicAdd(J.q.count, want);
+      first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+      if (want != 0 && first + want > J.cap) {
+        // no room: the round is left to the kernel that walks its shadow rays in place; what it was given of the queue's
+        // end is filled with rays that are over before they start
+        const uint32_t room = first < J.cap ? J.cap - first : 0u;
+        for (uint32_t i = lane; i < room; i += kWave) {
+          const uint32_t slot = first + i;
+          J.q.o[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+          J.q.d[slot] = make_float4(0.f, 0.f, 1.f, -1.f);
+          J.q.slot[slot] = (int)slot;
+          L.P.pend_w[slot] = f4(v3(1.f, 1.f, 1.f), (uint32_t)-1);
+          J.val[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        }
+        n_dummy += room;
+        if (lane == 0) J.deferred[atomicAdd(J.n_deferred, 1u)] = idx0;
+        n_ext = n_ext_before;
+        continue;
+      }
+      slot_next = first;
+    }
+#ifdef CASTER_BDPT_DIAG_KINDS   // diagnosis builds only: a bit per kind of join that is evaluated
+    for (int kind = 0; kind < 4; ++kind) if ((CASTER_BDPT_DIAG_KINDS >> kind) & 1) {
+#else
     for (int kind = 0; kind < 4; ++kind) {
+#endif
       {
         const int cs = nCamera - 1 > 0 ? nCamera - 1 : 0, lt = nLight - 1 > 0 ? nLight - 1 : 0;
         uint32_t mine = (uint32_t)(kind == 0 ? cs : kind == 1 ? (nLight >= 1 ? cs : 0) : kind == 2 ? (nCamera >= 1 ? lt : 0) : cs * lt);
@@ -532,34 +649,58 @@ __global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter
         __syncthreads();
       }
       const uint32_t wave_joins = s_end[kWave];
-      for (uint32_t j = lane; j < wave_joins; j += kWave) {
-        uint32_t lo = 0, hi = kWave - 1;  // the sample i with s_end[i] <= j < s_end[i + 1]
-        while (lo < hi) {
-          uint32_t mid = (lo + hi + 1) >> 1;
-          if (s_end[mid] <= j) lo = mid;
-          else hi = mid - 1;
+      for (uint32_t j0 = 0; j0 < wave_joins; j0 += kWave) {
+        const uint32_t j = j0 + lane;
+        JoinRay ray;
+        ray.want = false; ray.o = v3(0, 0, 0); ray.d = v3(0, 0, 1); ray.tmax = 0.f; ray.medium = -1;
+        V3 val = v3(0.f, 0.f, 0.f);
+        int target = -1;
+        if (j < wave_joins) {
+          uint32_t lo = 0, hi = kWave - 1;  // the sample i with s_end[i] <= j < s_end[i + 1]
+          while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) >> 1;
+            if (s_end[mid] <= j) lo = mid;
+            else hi = mid - 1;
+          }
+          const uint32_t i = lo;
+          const int nl = s_nl[i];
+          const uint32_t in_sample = j - s_end[i];
+          int s, t;
+          if (kind == 0) { s = 2 + (int)in_sample; t = 0; }
+          else if (kind == 1) { s = 2 + (int)in_sample; t = 1; }
+          else if (kind == 2) { s = 1; t = 2 + (int)in_sample; }
+          else { s = 2 + (int)(in_sample / (uint32_t)(nl - 1)); t = 2 + (int)(in_sample % (uint32_t)(nl - 1)); }
+          // draws of the joins before this one in the reference's order: three for every (s', 1) with
+          // 2 <= s' < s, three more past (s, 1)
+          uint32_t draws = nl >= 1 ? 3u * (uint32_t)(s - 2 > 0 ? s - 2 : 0) + (s >= 2 && t > 1 ? 3u : 0u) : 0u;
+          uint32_t jr = rng_skip(s_rng[i], draws);
+          int raster = -1;
+          V3 Lc = bdpt_connect<QUEUED>(S, st, L.stats, V, g0 + i, s, t, raster, jr, n_tr, ray);
+          if (QUEUED && ray.want) {
+            val = Lc;
+            target = s == 1 ? raster : s_pix[i];
+          } else if (!(has_inf(Lc) || has_nan(Lc) || is_black(Lc))) {
+            if (s == 1) {
+              splat(S, acc, raster, Lc);
+            } else {  // gathered in LDS: one add to the film per sample instead of one per join
+              atomicAdd(&s_own[i][0], Lc.x); atomicAdd(&s_own[i][1], Lc.y); atomicAdd(&s_own[i][2], Lc.z);
+            }
+          }
         }
-        const uint32_t i = lo;
-        const int nl = s_nl[i];
-        const uint32_t in_sample = j - s_end[i];
-        int s, t;
-        if (kind == 0) { s = 2 + (int)in_sample; t = 0; }
-        else if (kind == 1) { s = 2 + (int)in_sample; t = 1; }
-        else if (kind == 2) { s = 1; t = 2 + (int)in_sample; }
-        else { s = 2 + (int)(in_sample / (uint32_t)(nl - 1)); t = 2 + (int)(in_sample % (uint32_t)(nl - 1)); }
-        // draws of the joins before this one in the reference's order: three for every (s', 1) with
-        // 2 <= s' < s, three more past (s, 1)
-        uint32_t draws = nl >= 1 ? 3u * (uint32_t)(s - 2 > 0 ? s - 2 : 0) + (s >= 2 && t > 1 ? 3u : 0u) : 0u;
-        uint32_t jr = rng_skip(s_rng[i], draws);
-        int raster = -1;
-        V3 Lc = bdpt_connect(S, st, L.stats, V, g0 + i, s, t, raster, jr, n_tr);
-        if (has_inf(Lc) || has_nan(Lc) || is_black(Lc)) continue;
-        if (s == 1) {
-          splat(S, acc, raster, Lc);
-        } else {  // gathered in LDS: one add to the film per sample instead of one per join
-          atomicAdd(&s_own[i][0], Lc.x); atomicAdd(&s_own[i][1], Lc.y); atomicAdd(&s_own[i][2], Lc.z);
+        if (QUEUED && kind != 0) {
+          if (j < wave_joins) {
+            const uint32_t slot = slot_next + j;
+            // (a join that wants no ray: one that is over before it starts, tmax < 0)
+            J.q.o[slot] = f4(ray.o, __int_as_float(-1));
+            J.q.d[slot] = f4(ray.d, ray.want ? ray.tmax : -1.f);
+            J.q.slot[slot] = (int)slot;
+            L.P.pend_w[slot] = f4(v3(1.f, 1.f, 1.f), (uint32_t)ray.medium);
+            J.val[slot] = f4(val, __int_as_float(target));
+          }
+          n_dummy += (uint32_t)__popcll(lane_ballot(j < wave_joins && !ray.want));
         }
       }
+      if (QUEUED && kind != 0) slot_next += wave_joins;
     }
     __syncthreads();
     {
@@ -567,6 +708,7 @@ __global__ __launch_bounds__(kWave) void k_bdpt(LaunchCtx L, uint32_t first_iter
       if (live && !is_black(own)) splat(S, acc, (int)pixel, own);
     }
   }
+  if (QUEUED && lane == 0 && n_dummy) atomicAdd(J.unused, n_dummy);
   for (int off = 32; off > 0; off >>= 1) {
     n_tr += (uint32_t)__shfl_down((int)n_tr, off, 64);
     n_ext += (uint32_t)__shfl_down((int)n_ext, off, 64);

@@ -284,6 +284,8 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
 }
 
 constexpr int kDefaultStreams = 3;
+constexpr uint32_t kBdptJoinsPerSample = 32;  // join slots per sample of a launch of k_bdpt<true> (rounds that find no room are evaluated by k_bdpt<false>)
+constexpr size_t kBdptQueueNodes = 128;     // binary BVH nodes above which the joins' shadow rays are queued    // joins a wavefront stages before it asks for slots
 constexpr int kTrQueuePasses = 3;  // Tr() segments of the volumetric integrator's shadow rays done on queues
 constexpr int kMaxStreams = 8;
 // path state (80 B) + extension queues (2 x 52 B) + shadow (36 B) + probe (52 B) + three staging queues (3 x 36 B)
@@ -320,6 +322,8 @@ struct Lane {
   WalkAux aux{};
   StageArea stage{};
   BdptStore bdpt{};  // sub-path vertices of the bidirectional integrator, one column per lane of its grid
+  BdptJoins joins{}; // ... and its joins that wait for their shadow rays (bdpt_queues)
+  uint32_t* join_n = nullptr;   // joins the present launch of k_bdpt handed slots to
   Stats* stats = nullptr;
   hipEvent_t finish_done = nullptr;  // recorded after the lane's latest k_finish
   // batch under way between the two halves of its submission
@@ -347,6 +351,7 @@ struct caster_renderer {
   int shade_grid = 0;
   int bdpt_grid = 0;  // workgroups of k_bdpt (one sample per lane at a time)
   bool lt_queues = false;   // light tracing with its connection rays on queues (no density grid in the scene)
+  bool bdpt_queues = false; // bidirectional integrator with its joins' shadow rays on queues (large scenes without a density grid)
   bool probe_any = false;   // path tracer: probe rays ride the shadow queue as occlusion rays (few emitters, no environment)
   bool vpt_queues = false;  // volumetric integrator with its shadow and probe rays on queues
   bool vpt_hetero = false;  // ... in a scene with a density grid: the vertex in three phases (volpath_hetero.h)
@@ -435,7 +440,22 @@ static int alloc_lane(caster_renderer* r, Lane& ln) {
   if ((rc = alloc_queue(r, ln.ext[0], n, true, ln.counters + 0))) return rc;
   if ((rc = alloc_queue(r, ln.ext[1], n, true, ln.counters + 1))) return rc;
   // (with the probe rays among the shadow rays a path can append two entries to that queue, none to the other)
-  if ((rc = alloc_queue(r, ln.shadow, r->probe_any ? 2 * n : n, r->vpt_queues || r->lt_queues, ln.counters + 2))) return rc;
+  // (bidirectional integrator with queued joins: the shadow queues, the transmittance records and the staging regions
+  // of k_tr_step hold join slots, kBdptJoinsPerSample for every sample of a launch)
+  uint32_t joins_per_sample = kBdptJoinsPerSample;
+  if (const char* e = getenv("CASTER_BDPT_JOIN_SLOTS")) {   // (a knob for tests: few slots send rounds to the in-place kernel)
+    int v = atoi(e);
+    if (v >= 1 && v <= 64) joins_per_sample = (uint32_t)v;
+  }
+  if (r->bdpt_queues) {
+    // (a join slot costs some 170 bytes over the queues, records and staging regions; a lane takes an eighth of the free
+    // memory for them at most -- the staircase at 1080p: 33 Msamples/s in place, 37 with 16 slots per sample, 53 with 32 or 64)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      while (joins_per_sample > 4 && (size_t)joins_per_sample * n * 170 > free_b / 8) joins_per_sample /= 2;
+  }
+  const uint32_t nq = r->bdpt_queues ? joins_per_sample * n : n;
+  if ((rc = alloc_queue(r, ln.shadow, r->probe_any ? 2 * n : nq, r->vpt_queues || r->lt_queues || r->bdpt_queues, ln.counters + 2))) return rc;
   if ((rc = alloc_queue(r, ln.probe, r->probe_any ? kWave : n, true, ln.counters + 3))) return rc;
   if (r->vpt_queues || r->lt_queues) {
     if ((rc = alloc_queue(r, ln.tr1, n, true, ln.counters + 4))) return rc;
@@ -443,15 +463,26 @@ static int alloc_lane(caster_renderer* r, Lane& ln) {
     if ((rc = dev_alloc(r, &ln.P.pend_w, n))) return rc;
     if ((rc = dev_alloc(r, &ln.P.pend_v, n))) return rc;
   }
+  if (r->bdpt_queues) {
+    if ((rc = alloc_queue(r, ln.tr1, nq, true, ln.counters + 4))) return rc;
+    if ((rc = dev_alloc(r, &ln.P.pend_w, nq))) return rc;
+    ln.join_n = ln.counters + 5;
+    ln.joins.q = ln.shadow;
+    ln.joins.cap = nq;
+    ln.joins.unused = ln.counters + 6;
+    ln.joins.n_deferred = ln.counters + 7;
+    if ((rc = dev_alloc(r, &ln.joins.val, nq))) return rc;
+    if ((rc = dev_alloc(r, &ln.joins.deferred, (n + kWave - 1) / kWave))) return rc;   // (a launch covers an iteration: n samples)
+  }
   // every shade wavefront owns a staging region large enough for all paths it can be given
-  uint32_t rounds = (n + kWave - 1) / kWave;
+  uint32_t rounds = (nq + kWave - 1) / kWave;
   uint32_t per = (rounds + (uint32_t)r->shade_grid - 1) / (uint32_t)r->shade_grid;
   ln.stage.region_cap = (per + CASTER_SHADE_CHUNK) * kWave;   // (chunks dealt round-robin: up to one chunk more than an even share)
   ln.stage.shadow_region_cap = r->probe_any ? 2 * ln.stage.region_cap : ln.stage.region_cap;
   uint32_t cap = ln.stage.region_cap * (uint32_t)r->shade_grid;
-  if ((rc = alloc_queue(r, ln.stage.next, cap, false, nullptr))) return rc;
+  if ((rc = alloc_queue(r, ln.stage.next, r->bdpt_queues ? kWave : cap, false, nullptr))) return rc;   // (only k_tr_step stages anything there)
   if ((rc = alloc_queue(r, ln.stage.shadow, ln.stage.shadow_region_cap * (uint32_t)r->shade_grid, false, nullptr))) return rc;
-  if ((rc = alloc_queue(r, ln.stage.probe, r->probe_any ? kWave : cap, false, nullptr))) return rc;
+  if ((rc = alloc_queue(r, ln.stage.probe, r->probe_any || r->bdpt_queues ? kWave : cap, false, nullptr))) return rc;
   // stack spill columns, one per lane of the widest grid that walks the tree (the traversal kernel, and the shade-grid
   // and bidirectional kernels that walk in place); the traversal kernel keeps kTraceRays stacks per lane
   ln.aux.spill_stride = (uint32_t)std::max(r->walk_grid, std::max(r->shade_grid, r->bdpt_grid)) * kWave;
@@ -593,6 +624,12 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     // primitives without media, where walking a three-level tree in place beats three more
     // launches per round (Cornell box: 513 against 443 Msamples/s; 1.37 M triangles: 420 against 775)
     r->lt_queues = sc.integrator == IT_LT && !sc.has_heterogeneous && (sc.nodes.size() > 128 || !sc.media.empty());
+    // the bidirectional integrator sends the shadow rays of its joins through the traversal kernel on large scenes
+    // without a density grid (see BdptJoins; CASTER_BDPT_INKERNEL=1 in the environment keeps them in k_bdpt: a knob
+    // for tests and measurements)
+    const char* bdpt_in_kernel = getenv("CASTER_BDPT_INKERNEL");
+    r->bdpt_queues = sc.integrator == IT_BDPT && !sc.has_heterogeneous && sc.nodes.size() > kBdptQueueNodes &&
+                     !(bdpt_in_kernel && bdpt_in_kernel[0] == '1');
     const void* fn = sc.integrator == IT_AO ? (const void*)k_shade_ao
                      : sc.integrator == IT_VPT ? (r->vpt_hetero ? (const void*)k_vpth<0> : r->vpt_queues ? (const void*)k_shade_vptq : (const void*)k_shade_vpt)
                      : sc.integrator == IT_LT ? (r->lt_queues ? (const void*)k_shade_lt<true> : (const void*)k_shade_lt<false>)
@@ -623,8 +660,8 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     // one sample per lane at a time: as many wavefronts as are resident at once, within the
     // traversal grid (whose stack spill columns k_bdpt's lanes use)
     int per_cu = 4;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_bdpt, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    r->bdpt_grid = std::min(r->n_cu * std::min(per_cu, 16), r->walk_grid);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, r->bdpt_queues ? (const void*)k_bdpt<true> : (const void*)k_bdpt<false>, kWave, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    r->bdpt_grid = std::min(r->n_cu * std::min(per_cu, 24), r->walk_grid);
   }
   r->lanes.resize((size_t)n_streams);
   for (Lane& ln : r->lanes)
@@ -692,9 +729,53 @@ static int enqueue_batch(caster_renderer* r, uint32_t lane, bool tail, uint32_t 
   if (S.integrator == IT_BDPT) {
     // the whole sample runs in one kernel and splats into the film with float atomics (from every
     // stream at once, as light tracing does): nothing to submit in the second half
-    if (!tail) {
+    if (!tail && !r->bdpt_queues) {
       ScopedTimer t(r, st, CASTER_K_SHADE);
-      hipLaunchKernelGGL(k_bdpt, dim3(r->bdpt_grid), dim3(kWave), 0, st, L, first, n, r->acc, ln.aux, ln.bdpt);
+      hipLaunchKernelGGL(k_bdpt<false>, dim3(r->bdpt_grid), dim3(kWave), 0, st, L, first, n, 0u, total, r->acc, ln.aux, ln.bdpt, BdptJoins{},
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+      ln.batch_first = first; ln.batch_n = n;
+    }
+    if (!tail && r->bdpt_queues) {
+      // an iteration's worth of samples per launch (the join slots are sized for that), then the joins' shadow rays a
+      // Tr() segment per pass of the traversal kernel, then the splats
+      const uint32_t per_launch = (uint32_t)S.slots_per_iter;
+      for (uint32_t begin = 0; begin < total; begin += per_launch) {
+        const uint32_t end = begin + per_launch < total ? begin + per_launch : total;
+        {
+          ScopedTimer t(r, st, CASTER_K_SHADE);
+          hipLaunchKernelGGL(k_bdpt<true>, dim3(r->bdpt_grid), dim3(kWave), 0, st, L, first, n, begin, end, r->acc, ln.aux, ln.bdpt, ln.joins,
+                             (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+        }
+        hipLaunchKernelGGL(k_join_count, dim3(1), dim3(1), 0, st, ln.shadow.count, ln.joins.cap, ln.join_n, ln.joins.unused, ln.stats);
+        {
+          // the rounds that found the queue too full (none, as a rule), with their shadow rays walked in place
+          ScopedTimer t(r, st, CASTER_K_SHADE);
+          hipLaunchKernelGGL(k_bdpt<false>, dim3(r->bdpt_grid), dim3(kWave), 0, st, L, first, n, 0u, 0u, r->acc, ln.aux, ln.bdpt, BdptJoins{},
+                             (const uint32_t*)ln.joins.deferred, (const uint32_t*)ln.joins.n_deferred);
+        }
+        hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, ln.joins.n_deferred, 0u);
+        RayQueue* tq[2] = {&ln.shadow, &ln.tr1};
+        int tcur = 0;
+        for (int it = 0; it < kTrQueuePasses; ++it) {
+          hipLaunchKernelGGL(k_add_stat, dim3(1), dim3(1), 0, st, ln.stats, 3, (const uint32_t*)tq[tcur]->count);
+          hipLaunchKernelGGL(k_roll, dim3(1), dim3(1), 0, st, ln.stats, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
+                             ln.counters + 64 + 1 * kWorkShards * kWorkPad, (uint32_t)kWorkShards, r->work_init, 0u);
+          {
+            ScopedTimer t(r, st, CASTER_K_SHADOW);
+            hipLaunchKernelGGL(k_trace<false>, dim3(walk_grid / kTraceBlockWaves), dim3(kWave * kTraceBlockWaves), 0, st, L, *tq[tcur], aux_for(1));
+          }
+          hipLaunchKernelGGL(k_tr_step<false>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], *tq[tcur ^ 1], ln.stage);
+          hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, tq[tcur]->count, 0u);
+          tcur ^= 1;
+        }
+        hipLaunchKernelGGL(k_tr_finish<false>, dim3(shade_grid), dim3(kWave), 0, st, L, *tq[tcur], ln.aux);
+        hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, st, tq[tcur]->count, 0u);
+        {
+          ScopedTimer t(r, st, CASTER_K_PROBE);
+          hipLaunchKernelGGL(k_bdpt_resolve, dim3(r->n_cu * 8), dim3(256), 0, st, L, ln.joins, (const uint32_t*)ln.join_n, r->acc);
+        }
+      }
       ln.batch_first = first; ln.batch_n = n;
     }
     HIPCHECK(hipGetLastError());

@@ -91,3 +91,32 @@ def test_streams_batches_and_row_bands_add_up(caster, scenes):
         total += r.read_film(2)
         r.close()
     check_close(total, ref, "two row bands")
+
+
+@pytest.mark.parametrize("key", ["car_bdpt", "stairs_bdpt"])
+def test_joins_on_queues_in_place_and_left_over(caster, scenes, key, monkeypatch):
+    """On a large scene without a density grid the shadow rays of the joins go through the traversal kernel; rounds of
+    samples that find the join queue too full are evaluated afterwards by the kernel that walks them in place.  The
+    three ways -- queued (the default), nearly every round left over (one join slot per sample), everything in place
+    (CASTER_BDPT_INKERNEL=1) -- give the oracle's film to the integrator's tolerance and the oracle's ray counts."""
+    spp = SPP[key]
+    o = ol.Oracle(scenes[key])
+    counts = ol.Counts()
+    cpu = o.render(1, spp, 8, counts=counts)
+    c = counts.as_dict()
+    sc = caster.Scene(scenes[key])
+    for name, env in (("queued", {}), ("left over", {"CASTER_BDPT_JOIN_SLOTS": "1"}), ("in place", {"CASTER_BDPT_INKERNEL": "1"})):
+        for k in ("CASTER_BDPT_JOIN_SLOTS", "CASTER_BDPT_INKERNEL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = caster.Renderer(sc, 0, 2, 2)
+        r.render(1, spp, True)
+        gpu = r.read_film(2)
+        st = r.stats()
+        kt = r.kernel_times()
+        r.close()
+        assert st["stack_overflow"] == 0 and st["samples"] == sc.width * sc.height * spp
+        check_close(gpu, cpu, "%s, %s" % (key, name))
+        assert st["rays"][0] == c["rays"][0], name
+        assert st["rays"][3] == c["rays"][3], name
