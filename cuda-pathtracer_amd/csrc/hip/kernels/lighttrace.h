@@ -215,8 +215,14 @@ __global__ __launch_bounds__(kWave) void k_generate_lt(LaunchCtx L, RayQueue q, 
 }
 
 // One event of a light path (pathtracer.cu:1275-1374).
+// (the kernel that walks its connections in place takes 149 registers, three wavefronts per SIMD; held to the budget of
+// four it spills 32 values and the light tracer through a density grid runs 194 -> 217 Msamples/s, the Cornell box the
+// same; the queued kernel fits four as it is)
+#ifndef CASTER_LT_WAVES
+#define CASTER_LT_WAVES 4
+#endif
 template <bool QUEUED>
-__global__ __launch_bounds__(kWave) void k_shade_lt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage,
+__global__ __launch_bounds__(kWave, QUEUED ? 1 : CASTER_LT_WAVES) void k_shade_lt(LaunchCtx L, RayQueue cur, ShadeQueues out, StageArea stage,
                                                     WalkAux aux, float* acc) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
   Stack st{s_stack, aux.spill + (blockIdx.x * kWave + threadIdx.x), aux.spill_stride, 0};
