@@ -1,12 +1,12 @@
 # rocprofv3 kernel trace (three streams and one) + PMC passes of bench.py on another of the benchmark configurations:
-#   bash tools/gpu_prof_scene.sh NAME SCENE WIDTH HEIGHT DEPTH      -> gpurun_out/prof_NAME/{kernel_stats.csv,kernel_stats_one_stream.csv,pmc_summary.txt}
+#   [EXTRA_ARGS="--integrator bdpt"] bash tools/gpu_prof_scene.sh NAME SCENE WIDTH HEIGHT DEPTH      -> gpurun_out/prof_NAME/{kernel_stats.csv,kernel_stats_one_stream.csv,pmc_summary.txt}
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 NAME=$1
 OUT=gpurun_out/prof_$NAME
 rm -rf $OUT && mkdir -p $OUT
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu --no-exclusive --scene $2 --width $3 --height $4 --depth $5"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu --no-exclusive --scene $2 --width $3 --height $4 --depth $5 ${EXTRA_ARGS:-}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace1 -o t --output-format csv -- python3 $ARGS --streams 1 > $OUT/trace1.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $OUT/pmc1 -o p --output-format csv -- python3 $ARGS > $OUT/pmc1.log 2>&1
