@@ -608,10 +608,15 @@ __global__ __launch_bounds__(kWave, CASTER_BDPT_WAVES) void k_bdpt(LaunchCtx L, 
       for (int off = 32; off > 0; off >>= 1) want += (uint32_t)__shfl_xor((int)want, off, kWave);
       // (one atomic add per round, never a compare-and-swap loop: some thousand wavefronts retrying on one address
       // made the launch six times longer)
+      // (a queue that is full already is not added to: the counter then stays within one round per wavefront of the
+      // queue's length and cannot wrap around, however many joins the samples of a launch have)
       uint32_t first = 0u;
-      if (want != 0 && lane == 0) first = atomicAdd(J.q.count, want);
+      if (want != 0 && lane == 0) {
+        first = __atomic_load_n(J.q.count, __ATOMIC_RELAXED);
+        if (first < J.cap) first = atomicAdd(J.q.count, want);
+      }
       first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-      if (want != 0 && first + want > J.cap) {
+      if (want != 0 && (first >= J.cap || want > J.cap - first)) {
         // no room: the round is left to the kernel that walks its shadow rays in place; what it was given of the queue's
         // end is filled with rays that are over before they start
         const uint32_t room = first < J.cap ? J.cap - first : 0u;
