@@ -285,7 +285,7 @@ static void build_arrays(const Scene& sc, HostArrays& A) {
 
 constexpr int kDefaultStreams = 3;
 constexpr uint32_t kBdptJoinsPerSample = 32;  // join slots per sample of a launch of k_bdpt<true> (rounds that find no room are evaluated by k_bdpt<false>)
-constexpr size_t kBdptQueueNodes = 128;     // binary BVH nodes above which the joins' shadow rays are queued    // joins a wavefront stages before it asks for slots
+constexpr size_t kBdptQueueNodes = 0;       // binary BVH nodes above which the joins' shadow rays are queued (it pays on the Cornell box too: 88 -> 102 Msamples/s)    // joins a wavefront stages before it asks for slots
 constexpr int kTrQueuePasses = 3;  // Tr() segments of the volumetric integrator's shadow rays done on queues
 constexpr int kMaxStreams = 8;
 // path state (80 B) + extension queues (2 x 52 B) + shadow (36 B) + probe (52 B) + three staging queues (3 x 36 B)
@@ -624,11 +624,13 @@ static int begin_impl(const Scene& sc, int device_id, int iters_in_flight, int n
     // primitives without media, where walking a three-level tree in place beats three more
     // launches per round (Cornell box: 513 against 443 Msamples/s; 1.37 M triangles: 420 against 775)
     r->lt_queues = sc.integrator == IT_LT && !sc.has_heterogeneous && (sc.nodes.size() > 128 || !sc.media.empty());
-    // the bidirectional integrator sends the shadow rays of its joins through the traversal kernel on large scenes
+    // the bidirectional integrator sends the shadow rays of its joins through the traversal kernel in scenes
     // without a density grid (see BdptJoins; CASTER_BDPT_INKERNEL=1 in the environment keeps them in k_bdpt: a knob
     // for tests and measurements)
     const char* bdpt_in_kernel = getenv("CASTER_BDPT_INKERNEL");
-    r->bdpt_queues = sc.integrator == IT_BDPT && !sc.has_heterogeneous && sc.nodes.size() > kBdptQueueNodes &&
+    size_t queue_nodes = kBdptQueueNodes;
+    if (const char* e = getenv("CASTER_BDPT_QUEUE_NODES")) queue_nodes = (size_t)atol(e);   // (measurement knob)
+    r->bdpt_queues = sc.integrator == IT_BDPT && !sc.has_heterogeneous && sc.nodes.size() > queue_nodes &&
                      !(bdpt_in_kernel && bdpt_in_kernel[0] == '1');
     const void* fn = sc.integrator == IT_AO ? (const void*)k_shade_ao
                      : sc.integrator == IT_VPT ? (r->vpt_hetero ? (const void*)k_vpth<0> : r->vpt_queues ? (const void*)k_shade_vptq : (const void*)k_shade_vpt)

@@ -95,7 +95,7 @@ def test_streams_batches_and_row_bands_add_up(caster, scenes):
 
 @pytest.mark.parametrize("key", ["car_bdpt", "stairs_bdpt"])
 def test_joins_on_queues_in_place_and_left_over(caster, scenes, key, monkeypatch):
-    """On a large scene without a density grid the shadow rays of the joins go through the traversal kernel; rounds of
+    """Without a density grid the shadow rays of the joins go through the traversal kernel; rounds of
     samples that find the join queue too full are evaluated afterwards by the kernel that walks them in place.  The
     three ways -- queued (the default), nearly every round left over (one join slot per sample), everything in place
     (CASTER_BDPT_INKERNEL=1) -- give the oracle's film to the integrator's tolerance and the oracle's ray counts."""
