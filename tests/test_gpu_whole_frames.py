@@ -7,6 +7,7 @@ and the ray statistics with it.  The bar is bit equality: the closest hit is a f
 alone on both sides (smallest distance, then highest primitive index; boxes culled with a slack; a
 sphere candidate in front of its own bounding box rejected), so the order in which a wavefront happens
 to walk the tree cannot show."""
+import importlib
 import time
 
 import numpy as np
@@ -78,3 +79,43 @@ def test_density_grid_vertex_in_phases_equals_the_vertex_in_one_kernel(caster, t
     a, b = out["0"][1], out["1"][1]
     assert a["rays"][0] == b["rays"][0] and a["rays"][3] == b["rays"][3] and a["invalid"] == b["invalid"]
     assert 0 < a["rays"][2] < b["rays"][2]
+
+
+def test_density_grid_in_stripes_bands_and_uneven_batches(caster, tmp_path):
+    """The phased density-grid vertex where part of the slots of a batch lie outside the traced rows (interleaved
+    stripes of 8 scanlines, a band), where the image is not a multiple of the 8 x 8 tiles, and with batches of 1, 3 and
+    5 iterations on 1 to 3 streams: the stripes' films add up to the whole frame's bit for bit, and the whole frame does
+    not depend on the batching."""
+    sharding = importlib.import_module("cuda-pathtracer_amd.sharding")
+    path = gen_scenes.generate(str(tmp_path / "smoke"), "cornell_smoke", 1.0, 203, 149, 16)
+    sc = caster.Scene(path)
+    spp = 7
+    ref = None
+    for iters, streams in ((5, 1), (3, 2), (1, 3)):
+        r = caster.Renderer(sc, 0, iters, streams)
+        r.render(1, spp, True)
+        film = r.read_film(2)
+        st = r.stats()
+        r.close()
+        assert st["stack_overflow"] == 0 and st["samples"] == sc.width * sc.height * spp
+        if ref is None:
+            ref = film
+        else:
+            np.testing.assert_array_equal(film, ref)
+    total = np.zeros_like(ref)
+    for rank in range(3):
+        r = caster.Renderer(sc, 0, 2, 2)
+        r.set_row_stripes(*sharding.row_stripes(sc.height, rank, 3))
+        r.render(1, spp, True)
+        part = r.read_film(2)
+        r.close()
+        assert np.count_nonzero(part[total != 0]) == 0   # (disjoint scanlines)
+        total += part
+    np.testing.assert_array_equal(total, ref)
+    r = caster.Renderer(sc, 0, 4, 1)
+    r.set_rows(40, 97)
+    r.render(1, spp, True)
+    band = r.read_film(2)
+    r.close()
+    np.testing.assert_array_equal(band[40:97], ref[40:97])
+    assert not band[:40].any() and not band[97:].any()
