@@ -362,6 +362,30 @@ def test_several_devices_behind_one_handle(caster, key):
     assert rel_rmse(got, want) <= 1e-5
 
 
+@pytest.mark.parametrize("key", ["cornell_bdpt", "cornell_fog_bdpt", "cornell_lt", "cornell_fog_lt"])
+def test_splatting_integrators_behind_a_device_group(caster, tmp_path, key):
+    """Light tracing and BDPT through caster_begin_multi ([0, 0, 0]) in both shard modes: a part's samples splat
+    anywhere in the image, so the parts' whole films are added; the sum is the one-device film to the tolerance of the
+    splatting integrators, the rays are the same."""
+    import gen_scenes
+    path = gen_scenes.generate(str(tmp_path / key), key, 1.0, 160, 120, 8)
+    sc = caster.Scene(path)
+    one = caster.Renderer(sc, 0, 2)
+    one.render(1, 8, True)
+    want = one.read_film(2)
+    rays = one.stats()["rays"]
+    one.close()
+    assert want.sum() > 0
+    for shard in ("tile", "spp"):
+        g = caster.Renderer(sc, [0, 0, 0], 2, 2, shard=shard)
+        g.render(1, 8, True)
+        got = g.read_film(2)
+        st = g.stats()
+        g.close()
+        assert rel_rmse(got, want) <= 1e-5, shard
+        assert st["rays"] == rays and st["stack_overflow"] == 0, shard
+
+
 def test_device_group_of_eight(caster, tmp_path):
     """caster_begin_multi with EIGHT entries (all on the one GPU of the test box: eight host threads, eight
     renderers, seven film copies and adds): both shard modes against one device, statistics of the whole job, and
