@@ -500,10 +500,15 @@ __device__ inline uint32_t rng_skip(uint32_t x, uint32_t k) {
 // registers, 83 at 168, 99 at 128, 105 at 96, 92 at 80).
 #define CASTER_BDPT_WAVES 5
 #endif
+// (the kernel that queues its joins' shadow rays carries no tree walk in its join loop and does best with the budget of
+// four: 128 registers; benchmark scene 191 -> 194 Msamples/s, staircase 53 -> 56, Cornell box 102 -> 117)
+#ifndef CASTER_BDPT_QUEUED_WAVES
+#define CASTER_BDPT_QUEUED_WAVES 4
+#endif
 // Samples [begin, end) of the batch (multiples of the wavefront size), or -- `rounds` given -- the rounds of 64 samples
 // that start at the *n_rounds sample indices listed there.  QUEUED: see BdptJoins.
 template <bool QUEUED>
-__global__ __launch_bounds__(kWave, CASTER_BDPT_WAVES) void k_bdpt(LaunchCtx L, uint32_t first_iter, uint32_t n_iter, uint32_t begin,
+__global__ __launch_bounds__(kWave, QUEUED ? CASTER_BDPT_QUEUED_WAVES : CASTER_BDPT_WAVES) void k_bdpt(LaunchCtx L, uint32_t first_iter, uint32_t n_iter, uint32_t begin,
                                                                     uint32_t end, float* acc, WalkAux aux, BdptStore V, BdptJoins J,
                                                                     const uint32_t* rounds, const uint32_t* n_rounds) {
   __shared__ uint2 s_stack[kLdsDepth][kWave];
